@@ -1,0 +1,99 @@
+"""ctypes binding of libgodot_hip.so (the C ABI declared in include/godot_hip.h).
+
+There is no fallback: if the shared library is missing the import fails with
+instructions to build it, and every call that returns a non-zero code raises
+GodotError with the library's message.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgodot_hip.so')
+
+c_f64p = ctypes.c_void_p      # device pointers travel as integers
+c_i64p = ctypes.c_void_p
+c_i32p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_f64 = ctypes.c_double
+c_int = ctypes.c_int
+c_size = ctypes.c_size_t
+c_stream = ctypes.c_void_p
+c_ws = ctypes.c_void_p
+
+
+class GodotError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'godot_amd: %s is missing. Build it with `make -C godot_amd/csrc` or '
+        '`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc; '
+        'cross-compiles for gfx950 without a GPU).' % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_CELLS = [c_f64p, c_i64, c_i64p, c_i64p]          # we, nph, lo, hi
+
+# name -> (restype, argtypes); int-returning functions are error-checked
+SIGNATURES = {
+    'godot_last_error': (ctypes.c_char_p, []),
+    'godot_version': (c_int, []),
+    'godot_cell_fit': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,
+                                        c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_cell_loglike': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_int, c_f64p, c_stream]),
+    'godot_cell_logpdf': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_int, c_int,
+                                           c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_profile_quantiles': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_f64, c_f64, c_f64p, c_f64p,
+                                        c_f64p, c_stream]),
+    'godot_lightcurve_rows': (c_int, [c_f64p] * 7 + [c_i64, c_f64, c_f64p, c_stream]),
+    'godot_cell_beta_max': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,
+                                             c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_exposure_workspace_bytes': (c_size, [c_i64]),
+    'godot_exposure_at': (c_int, [c_f64p] * 4 + [c_i64, c_f64, c_f64, c_f64p, c_i64, c_int]
+                          + [c_f64p] * 4 + [c_ws, c_size, c_stream]),
+    'godot_bin_photons': (c_int, [c_f64p, c_i64, c_f64, c_f64p, c_i64, c_i64p, c_i64p, c_i64p,
+                                  c_stream]),
+    'godot_cell_moments': (c_int, _CELLS + [c_i64, c_f64p, c_f64p, c_stream]),
+    'godot_select_workspace_bytes': (c_size, [c_i64]),
+    'godot_select_cells': (c_int, [c_f64p, c_i64, c_f64, c_i64p, c_i64p, c_ws, c_size, c_stream]),
+    'godot_gather_f64': (c_int, [c_f64p, c_i64p, c_i64, c_f64p, c_stream]),
+    'godot_gather_i64': (c_int, [c_i64p, c_i64p, c_i64, c_i64p, c_stream]),
+    'godot_rfft_workspace_bytes': (c_size, [c_i64]),
+    'godot_rfft_f64': (c_int, [c_f64p, c_i64, c_i64, c_f64p, c_ws, c_size, c_stream]),
+    'godot_power_spectrum_workspace_bytes': (c_size, [c_i64]),
+    'godot_power_spectrum_fft': (c_int, [c_f64p] * 6 + [c_i64, c_i64] + [c_f64p] * 4
+                                 + [c_ws, c_size, c_stream]),
+    'godot_power_spectrum_simple': (c_int, [c_f64p] * 3 + [c_i64, c_f64p, c_f64p, c_ws, c_size,
+                                                           c_stream]),
+    'godot_trigsum_cells': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_i64, c_int, c_f64,
+                                             c_f64p, c_stream]),
+    'godot_fit_harmonics': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_i64, c_f64p, c_stream]),
+    'godot_z2m_workspace_bytes': (c_size, [c_i64]),
+    'godot_z2m': (c_int, [c_f64p, c_f64p, c_i64, c_f64, c_f64, c_i64, c_i64, c_int, c_f64p, c_f64p,
+                          c_ws, c_size, c_stream]),
+}
+
+MISSING = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.godot_last_error().decode('utf-8', 'replace')
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise GodotError on failure."""
+    if name in MISSING:
+        raise GodotError('%s is not exported by %s' % (name, LIB_PATH))
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise GodotError('%s failed (%d): %s' % (name, rc, last_error()))
+    return rc

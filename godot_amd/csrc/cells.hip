@@ -1,0 +1,993 @@
+// Per-cell weighted-Poisson likelihood kernels (gfx950).
+//
+// Layout: photon weights of all cells in one array `we`; cell c owns
+// we[lo[c] .. hi[c]-1].  A "team" of T lanes (T = 4, 16 or 64, aligned inside
+// a 64-lane wavefront) owns one cell.  The team streams the cell's weights
+// from HBM exactly once into registers (R per lane) and runs every pass of
+// the fixed-schedule Newton/Halley maximiser, the TS and the support search
+// out of registers; per-pass sums are combined with wavefront butterflies.
+// Cells that do not fit T*R registers re-read their weights per pass (they
+// then come from L2, which a cell of that size still fits).
+#include "common.hpp"
+
+namespace {
+
+struct CellArgs {
+    const double *we;
+    int64_t nph;
+    const int64_t *lo;
+    const int64_t *hi;
+    const double *S;
+    const double *B;
+    int64_t ncell;
+    int swap;
+};
+
+// Weights of one cell as seen by one lane of its team.
+template <int T, int R>
+struct CellData {
+    double w[R];
+    const double *p;
+    int64_t n;
+    int lane;
+    bool in_regs;
+    bool swap;
+
+    __device__ __forceinline__ double ld(int64_t i) const
+    {
+        double v = p[i];
+        return swap ? 1.0 - v : v;
+    }
+
+    __device__ __forceinline__ void load(const double *base, int64_t n_, int lane_, bool swap_)
+    {
+        p = base;
+        n = n_;
+        lane = lane_;
+        swap = swap_;
+        in_regs = n <= (int64_t)T * R;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int64_t i = lane + (int64_t)r * T;
+                w[r] = (i < n) ? ld(i) : 0.0;
+            }
+        }
+    }
+
+    // acc[k] = sum over the cell's photons of what f adds, for k < NS.
+    template <int NS, class F>
+    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + (int64_t)r * T < n) f(w[r], acc);
+        } else {
+            for (int64_t i = lane; i < n; i += T) f(ld(i), acc);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
+    }
+
+    template <class F>
+    __device__ __forceinline__ double maxof(F f) const
+    {
+        double m = -INFINITY;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + (int64_t)r * T < n) m = fmax(m, f(w[r]));
+        } else {
+            for (int64_t i = lane; i < n; i += T) m = fmax(m, f(ld(i)));
+        }
+        return team_max<T>(m);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// get_max with the background level fixed: reference core.py:632-691.
+// g = guess - 1, b = beta - 1 (the reference's zero-based parameters).
+// ---------------------------------------------------------------------------
+
+// f(a) = sum w/(t2 + a w) - S with t2 = 1 + b (1 - w)
+template <int T, int R>
+__device__ double score(const CellData<T, R> &cd, double a, double b, double S)
+{
+    double acc[1];
+    cd.template sums<1>([=](double w, double (&s)[1]) {
+        double t2 = 1.0 + b * (1.0 - w);
+        s[0] += w / (t2 + a * w);
+    }, acc);
+    return acc[0] - S;
+}
+
+// scipy.optimize.brentq (Zeros/brentq.c) on the score function with beta = 1,
+// as the reference's get_max_numerical uses it (core.py:728-739).
+template <int T, int R>
+__device__ double max_numerical(const CellData<T, R> &cd, double S, int &flags)
+{
+    flags |= GODOT_F_BRENT;
+    if (score(cd, -1.0, 0.0, S) < 0) {
+        flags |= GODOT_F_AT_ZERO;
+        return 0.0;
+    }
+    double a0 = -1.0, amax = 0.0;
+    for (int i = 0; i < 12; ++i) {
+        if (score(cd, amax, 0.0, S) < 0) break;
+        a0 = amax;
+        amax = 2 * amax + 1;
+    }
+    const double xtol = 1e-3, rtol = 8.881784197001252e-16;
+    double xpre = a0, xcur = amax, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    double fpre = score(cd, xpre, 0.0, S);
+    double fcur = score(cd, xcur, 0.0, S);
+    if (fpre == 0) return xpre + 1;
+    if (fcur == 0) return xcur + 1;
+    if (signbit(fpre) == signbit(fcur)) {
+        flags |= GODOT_F_FAILED;   // the reference raises ValueError here
+        return qnan();
+    }
+    for (int it = 0; it < 100; ++it) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        double delta = (xtol + rtol * fabs(xcur)) / 2;
+        double sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur + 1;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = score(cd, xcur, 0.0, S);
+    }
+    flags |= GODOT_F_FAILED;
+    return qnan();
+}
+
+template <int T, int R>
+__device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, double beta, int &flags)
+{
+    double g = guess - 1;
+    double b = beta - 1;
+    for (int depth = 0;; ++depth) {
+        flags = (flags & ~GODOT_F_DEPTH_MASK) | (depth << 1);
+        // derivative at alpha = 0 (core.py:639-644)
+        if (score(cd, -1.0, b, S) < 0) {
+            flags |= GODOT_F_AT_ZERO;
+            return 0.0;
+        }
+        double a = g;
+        double acc[3];
+        auto pass2 = [&](double a_) {
+            cd.template sums<2>([=](double w, double (&s)[2]) {
+                double t2 = 1.0 + b * (1.0 - w);
+                double r = w / (t2 + a_ * w);
+                s[0] += r;
+                s[1] += r * r;
+            }, reinterpret_cast<double (&)[2]>(acc));
+        };
+        // Newton 1: keep away from zero flux (core.py:649-655)
+        pass2(a);
+        a = a + (acc[0] - S) / acc[1];
+        if (a < 0 - 1) a = 0.2 - 1;
+        // Newton 2 (core.py:658-664)
+        pass2(a);
+        a = a + (acc[0] - S) / acc[1];
+        if (a < 0.05 - 1) a = 0.05 - 1;
+        // Newton 3 (core.py:667-671)
+        pass2(a);
+        a = pymax(0.0 - 1, a + (acc[0] - S) / acc[1]);
+        double alast = a;
+        // Halley (core.py:674-680)
+        {
+            double a_ = a;
+            cd.template sums<3>([=](double w, double (&s)[3]) {
+                double t2 = 1.0 + b * (1.0 - w);
+                double r = w / (t2 + a_ * w);
+                double r2 = r * r;
+                s[0] += r;
+                s[1] += r2;
+                s[2] += r2 * r;
+            }, acc);
+        }
+        {
+            double f1 = acc[0] - S, f2 = acc[1], f3 = 2 * acc[2];
+            a = pymax(0.0 - 1, a + 2 * f1 * f2 / (2 * f2 * f2 - f1 * f3));
+        }
+        // slow convergence or a far-away start: try again (core.py:684-689)
+        if ((fabs(a - alast) > 0.05) || (fabs(g - a) > 10)) {
+            if (depth > 2) return max_numerical(cd, S, flags);
+            g = (a + 1) - 1;
+            b = (b + 1) - 1;
+            continue;
+        }
+        return a + 1;
+    }
+}
+
+// logL(alpha) = sum log(alpha w + (1 - w)) - S alpha   (core.py:353-364)
+template <int T, int R>
+__device__ double loglike(const CellData<T, R> &cd, double S, double alpha)
+{
+    double acc[1];
+    cd.template sums<1>([=](double w, double (&s)[1]) {
+        s[0] += log(w * alpha + (1.0 - w));
+    }, acc);
+    return acc[0] - S * alpha;
+}
+
+// 2 (logL(aopt) - logL(0))   (core.py:982-994)
+template <int T, int R>
+__device__ double test_statistic(const CellData<T, R> &cd, double S, double aopt)
+{
+    if (S == 0 || aopt == 0) return 0.0;
+    double acc[2];
+    cd.template sums<2>([=](double w, double (&s)[2]) {
+        double iw = 1.0 - w;
+        s[0] += log(w * aopt + iw);
+        s[1] += log(iw);
+    }, acc);
+    return 2 * ((acc[0] - S * aopt) - acc[1]);
+}
+
+template <int T>
+__device__ __forceinline__ bool cell_setup(const CellArgs &p, int64_t &cell, int &lane,
+                                           int64_t &lo, int64_t &n, double &S, double &B, bool &bad)
+{
+    lane = threadIdx.x & (T - 1);
+    cell = (int64_t)blockIdx.x * (blockDim.x / T) + (threadIdx.x / T);
+    if (cell >= p.ncell) return false;
+    lo = p.lo[cell];
+    int64_t hi = p.hi[cell];
+    bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+    n = bad ? 0 : hi - lo;
+    S = p.S[cell];
+    B = p.B ? p.B[cell] : 0.0;
+    if (p.swap) {
+        double t = S; S = B; B = t;
+    }
+    return true;
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_fit_kernel(CellArgs p, const double *guess, double guess0,
+                                                       const double *beta, double beta0,
+                                                       double *alpha, double *ts, int32_t *flags)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, p.swap != 0);
+    int fl = 0;
+    double a, t = 0.0;
+    if (bad) {
+        fl = GODOT_F_FAILED;
+        a = t = qnan();
+    } else {
+        a = fit_alpha(cd, S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
+        if (ts) t = test_statistic(cd, S, a);
+    }
+    if (lane == 0) {
+        alpha[cell] = a;
+        if (ts) ts[cell] = t;
+        if (flags) flags[cell] = fl;
+    }
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_loglike_kernel(CellArgs p, const double *alpha, double *out)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, p.swap != 0);
+    double v = bad ? qnan() : loglike(cd, S, alpha[cell]);
+    if (lane == 0) out[cell] = v;
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *wsum, double *w2sum)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    p.S = wsum;   // unused by this kernel; keeps cell_setup's loads in bounds
+    p.B = nullptr;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, false);
+    double acc[2];
+    cd.template sums<2>([](double w, double (&s)[2]) {
+        s[0] += w;
+        s[1] += w * w;
+    }, acc);
+    if (lane == 0) {
+        wsum[cell] = bad ? qnan() : acc[0];
+        w2sum[cell] = bad ? qnan() : acc[1];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// get_beta_max (core.py:741-823) and log_profile_likelihood (core.py:391-406)
+// ---------------------------------------------------------------------------
+template <int T, int R>
+__device__ double fit_beta(const CellData<T, R> &cd, double B, double alpha, double guess, int &flags)
+{
+    if (isnan(alpha)) return 1.0;
+    if (cd.n == 0) return 0.0;
+    if (alpha == 0) return (double)cd.n / B;
+    double al = alpha - 1;
+    double g = guess - 1;
+    for (int depth = 0;; ++depth) {
+        flags = (flags & ~GODOT_F_DEPTH_MASK) | (depth << 1);
+        double acc[3];
+        cd.template sums<1>([](double w, double (&s)[1]) { s[0] += (1.0 - w) / w; },
+                            reinterpret_cast<double (&)[1]>(acc));
+        if (acc[0] < B * (1 + al)) {
+            flags |= GODOT_F_AT_ZERO;
+            return 0.0;
+        }
+        double b = g;
+        const double lows[3] = {0.2 - 1, 0.05 - 1, 0.02 - 1};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double b_ = b;
+            cd.template sums<2>([=](double w, double (&s)[2]) {
+                double iw = 1.0 - w;
+                double r = iw / ((1.0 + al * w) + b_ * iw);
+                s[0] += r;
+                s[1] += r * r;
+            }, reinterpret_cast<double (&)[2]>(acc));
+            b = b + (acc[0] - B) / acc[1];
+            b = pymax(lows[k], b);
+        }
+        double blast = b;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double b_ = b;
+            cd.template sums<3>([=](double w, double (&s)[3]) {
+                double iw = 1.0 - w;
+                double r = iw / ((1.0 + al * w) + b_ * iw);
+                double r2 = r * r;
+                s[0] += r;
+                s[1] += r2;
+                s[2] += r2 * r;
+            }, acc);
+            double f1 = acc[0] - B, f2 = acc[1], f3 = 2 * acc[2];
+            double nb = pymax(0.0 - 1, b + 2 * f1 * f2 / (2 * f2 * f2 - f1 * f3));
+            if (k == 0) {
+                // step limiter of the first Halley iteration (core.py:799-803)
+                if (fabs(nb - b) > 10) b = 2 * b + 1;
+                else b = nb;
+                blast = b;
+            } else {
+                b = nb;
+            }
+        }
+        if ((fabs(b - blast) > 0.05) || (fabs(g - b) > 10) || (b == -1)) {
+            if (depth > 2) {
+                flags |= GODOT_F_FAILED;   // the reference raises ValueError
+                return qnan();
+            }
+            al = (al + 1) - 1;
+            g = (b + 1) - 1;
+            continue;
+        }
+        return b + 1;
+    }
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_beta_kernel(CellArgs p, const double *alpha, double alpha0,
+                                                        const double *guess, double guess0,
+                                                        double *beta, double *lprof, int32_t *flags)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, p.swap != 0);
+    int fl = 0;
+    double bt, lp = 0.0;
+    if (bad) {
+        fl = GODOT_F_FAILED;
+        bt = lp = qnan();
+    } else {
+        double al = alpha ? alpha[cell] : alpha0;
+        bt = fit_beta(cd, B, al, guess ? guess[cell] : guess0, fl);
+        if (lprof) {
+            double b = bt - 1, a = al - 1;
+            double acc[1];
+            cd.template sums<1>([=](double w, double (&s)[1]) {
+                s[0] += log((1.0 + b) + w * (a - b));
+            }, acc);
+            lp = acc[0] - S * (1 + a) - B * (1 + b);
+        }
+    }
+    if (lane == 0) {
+        beta[cell] = bt;
+        if (lprof) lprof[cell] = lp;
+        if (flags) flags[cell] = fl;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// get_logpdf (core.py:851-932): adaptive support + npt-point profile.
+// One workgroup = LP_CH cells.  Phase 1 (support search) runs one 16-lane
+// team per cell; phase 2 spreads the LP_CH*npt grid points over all 256
+// threads, each thread summing over its cell's photons; phase 3 checks the
+// grid maximum against llmax and re-centres the cell if they disagree.
+// ---------------------------------------------------------------------------
+constexpr int LP_CH = 16;
+constexpr int LP_T = 16;
+constexpr int LP_R = 4;
+constexpr int LP_MAX_RECENTRE = 50;
+
+struct Support {
+    double amin, amax, llmax;
+};
+
+template <int T, int R>
+__device__ Support support_search(const CellData<T, R> &cd, double S, double aopt, double dlogl,
+                                  bool include_zero)
+{
+    Support r;
+    double amin = 0.0, amax, llmax;
+    double acc[2];
+    // Newton step on logL(a) - llmax + dlogl = 0
+    auto f0f1 = [&](double a) {
+        cd.template sums<2>([=](double w, double (&s)[2]) {
+            double t = a * w + (1.0 - w);
+            s[0] += log(t);
+            s[1] += w / t;
+        }, acc);
+    };
+    if (aopt == 0) {   // core.py:869-880
+        cd.template sums<2>([](double w, double (&s)[2]) {
+            double iw = 1.0 - w;
+            s[0] += log(iw);
+            s[1] += w / iw;
+        }, acc);
+        llmax = acc[0];
+        amax = pymax(0.0, -(llmax + dlogl) / (acc[1] - S));
+        for (int i = 0; i < 10; ++i) {
+            f0f1(amax);
+            double f0 = acc[0] - amax * S + dlogl - llmax;
+            double f1 = acc[1] - S;
+            amax = amax - f0 / f1;
+            if (fabs(f0) < 0.1) break;
+        }
+    } else {           // core.py:881-895
+        cd.template sums<2>([=](double w, double (&s)[2]) {
+            double t = aopt * w + (1.0 - w);
+            s[0] += log(t);
+            double q = w / t;
+            s[1] += q * q;
+        }, acc);
+        llmax = acc[0] - S * aopt;
+        double f2 = fabs(acc[1]);
+        amax = aopt + sqrt(2 * dlogl / f2);
+        for (int i = 0; i < 5; ++i) {
+            f0f1(amax);
+            double f0 = acc[0] - amax * S + dlogl - llmax;
+            double f1 = acc[1] - S;
+            amax = amax - f0 / f1;
+            if (fabs(f0) < 0.1) break;
+        }
+        if (!include_zero && aopt > 0) {   // core.py:897-914
+            double min_a = cd.maxof([](double w) { return 1 - 1. / w; }) + 1e-6;
+            amin = pymax(min_a, aopt - sqrt(2 * dlogl / f2));
+            for (int i = 0; i < 5; ++i) {
+                f0f1(amin);
+                double f0 = acc[0] - amin * S + dlogl - llmax;
+                double f1 = acc[1] - S;
+                amin = pymax(min_a, amin - f0 / f1);
+                if (fabs(f0) < 0.1) break;
+            }
+        }
+    }
+    amin = pymax(0.0, amin);   // core.py:916
+    r.amin = amin;
+    r.amax = amax;
+    r.llmax = llmax;
+    return r;
+}
+
+// numpy.linspace(amin, amax, npt)[i]
+__device__ __forceinline__ double grid_point(double amin, double amax, double step, int i, int npt)
+{
+    if (i == npt - 1 && npt > 1) return amax;
+    return __dadd_rn(__dmul_rn((double)i, step), amin);
+}
+
+__global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const double *aopt_in, double dlogl,
+                                                          int npt, int include_zero, double *dom,
+                                                          double *cod, int32_t *flags)
+{
+    extern __shared__ double s_cod[];   // [LP_CH][npt]
+    __shared__ double s_amin[LP_CH], s_amax[LP_CH], s_step[LP_CH], s_llmax[LP_CH], s_S[LP_CH],
+        s_aopt[LP_CH];
+    __shared__ int64_t s_lo[LP_CH], s_n[LP_CH];
+    __shared__ int s_state[LP_CH];   // 0 = to do, 1 = done, 2 = absent/failed
+    __shared__ int s_flags[LP_CH];
+
+    const int tid = threadIdx.x;
+    const int team = tid / LP_T;
+    const int lane = tid % LP_T;
+    const int64_t cell0 = (int64_t)blockIdx.x * LP_CH;
+    const int64_t cell = cell0 + team;
+    const bool have = cell < p.ncell;
+    const bool swap = p.swap != 0;
+
+    CellData<LP_T, LP_R> cd;
+    double S = 0.0;
+    int fl = 0;
+    bool bad = false;
+    if (have) {
+        int64_t lo = p.lo[cell], hi = p.hi[cell];
+        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        int64_t n = bad ? 0 : hi - lo;
+        S = swap ? p.B[cell] : p.S[cell];
+        cd.load(p.we + lo, n, lane, swap);
+        double a0;
+        if (bad) {
+            a0 = qnan();
+            fl = GODOT_F_FAILED;
+        } else if (aopt_in) {
+            a0 = aopt_in[cell];
+        } else {
+            a0 = fit_alpha(cd, S, 1.0, 1.0, fl);
+            if (fl & GODOT_F_FAILED) bad = true;
+        }
+        if (lane == 0) {
+            s_lo[team] = lo;
+            s_n[team] = n;
+            s_S[team] = S;
+            s_aopt[team] = a0;
+            s_state[team] = bad ? 2 : 0;
+            s_flags[team] = fl;
+        }
+    } else {
+        cd.load(p.we, 0, lane, swap);
+        if (lane == 0) {
+            s_state[team] = 2;
+            s_n[team] = 0;
+            s_lo[team] = 0;
+            s_flags[team] = 0;
+        }
+    }
+    __syncthreads();
+
+    for (int round = 0; round <= LP_MAX_RECENTRE; ++round) {
+        // phase 1: support of the cells still to do
+        if (s_state[team] == 0) {
+            Support sp = support_search(cd, S, s_aopt[team], dlogl, include_zero != 0);
+            if (lane == 0) {
+                s_amin[team] = sp.amin;
+                s_amax[team] = sp.amax;
+                s_llmax[team] = sp.llmax;
+                s_step[team] = (npt > 1) ? (sp.amax - sp.amin) / (double)(npt - 1) : 0.0;
+            }
+        }
+        __syncthreads();
+        // phase 2: grid evaluation, (cell, point) pairs over all threads
+        for (int k = tid; k < LP_CH * npt; k += blockDim.x) {
+            int c = k / npt, i = k - c * npt;
+            if (s_state[c] != 0) continue;
+            double a = grid_point(s_amin[c], s_amax[c], s_step[c], i, npt);
+            const double *w = p.we + s_lo[c];
+            int64_t n = s_n[c];
+            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+            int64_t j = 0;
+            for (; j + 4 <= n; j += 4) {
+                double w0 = w[j], w1 = w[j + 1], w2 = w[j + 2], w3 = w[j + 3];
+                if (swap) { w0 = 1.0 - w0; w1 = 1.0 - w1; w2 = 1.0 - w2; w3 = 1.0 - w3; }
+                acc0 += log(w0 * a + (1.0 - w0));
+                acc1 += log(w1 * a + (1.0 - w1));
+                acc2 += log(w2 * a + (1.0 - w2));
+                acc3 += log(w3 * a + (1.0 - w3));
+            }
+            for (; j < n; ++j) {
+                double w0 = w[j];
+                if (swap) w0 = 1.0 - w0;
+                acc0 += log(w0 * a + (1.0 - w0));
+            }
+            s_cod[k] = ((acc0 + acc1) + (acc2 + acc3)) - s_S[c] * a;
+        }
+        __syncthreads();
+        // phase 3: agreement of the grid maximum with llmax (core.py:923-929)
+        int pending = 0;
+        if (s_state[team] == 0) {
+            double best = -INFINITY;
+            int ibest = npt;
+            bool anynan = false;
+            for (int i = lane; i < npt; i += LP_T) {
+                double v = s_cod[team * npt + i];
+                if (isnan(v)) anynan = true;
+                if (v > best) {   // strided scan keeps the first maximum per lane
+                    best = v;
+                    ibest = i;
+                }
+            }
+#pragma unroll
+            for (int o = LP_T / 2; o > 0; o >>= 1) {
+                double ob = __shfl_xor(best, o, WAVE);
+                int oi = __shfl_xor(ibest, o, WAVE);
+                int on = __shfl_xor((int)anynan, o, WAVE);
+                anynan = anynan || on;
+                if (ob > best || (ob == best && oi < ibest)) {
+                    best = ob;
+                    ibest = oi;
+                }
+            }
+            // numpy's argmax returns the first NaN if there is one, and the
+            // reference's comparison is then false: the grid is accepted.
+            if (ibest >= npt) ibest = 0;
+            bool agree = anynan || !(fabs(best - s_llmax[team]) > 0.05);
+            if (agree) {
+                if (lane == 0) s_state[team] = 1;
+            } else if (round == LP_MAX_RECENTRE) {
+                if (lane == 0) {
+                    s_state[team] = 2;
+                    s_flags[team] |= GODOT_F_FAILED;
+                }
+            } else {
+                if (lane == 0) {
+                    s_aopt[team] = grid_point(s_amin[team], s_amax[team], s_step[team], ibest, npt);
+                    s_flags[team] |= GODOT_F_RECENTRED;
+                }
+                pending = 1;
+            }
+        }
+        if (!__syncthreads_or(pending)) break;
+    }
+
+    // write-out, coalesced over (cell, point)
+    for (int k = tid; k < LP_CH * npt; k += blockDim.x) {
+        int c = k / npt, i = k - c * npt;
+        int64_t cg = cell0 + c;
+        if (cg >= p.ncell) break;
+        double d, v;
+        if (s_state[c] == 1) {
+            d = grid_point(s_amin[c], s_amax[c], s_step[c], i, npt);
+            v = s_cod[k] - s_llmax[c];
+        } else {
+            d = v = qnan();
+        }
+        dom[cg * npt + i] = d;
+        cod[cg * npt + i] = v;
+    }
+    if (flags && have && lane == 0) flags[cell] = s_flags[team];
+}
+
+// ---------------------------------------------------------------------------
+// Quantiles of the cached profiles (core.py:1229, 1247-1256); one wavefront
+// per cell, profile staged in LDS.
+// ---------------------------------------------------------------------------
+constexpr int PQ_MAX_NPT = 1024;
+
+__global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *dom, const double *cod,
+                                                                int64_t ncell, int npt, double c_lo,
+                                                                double c_hi, double *aguess,
+                                                                double *xlo, double *xhi)
+{
+    extern __shared__ double sm[];   // per wave: dom[npt], pdf[npt], cdf[npt]
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int64_t cell = (int64_t)blockIdx.x * (blockDim.x / WAVE) + wave;
+    const bool active = cell < ncell;
+    double *s_dom = sm + (size_t)wave * 3 * npt;
+    double *s_pdf = s_dom + npt;
+    double *s_cdf = s_pdf + npt;
+
+    // argmax of cod (first maximum) and pdf = exp(cod)
+    double best = -INFINITY;
+    int ibest = npt;
+    if (active) {
+        const double *d = dom + cell * npt;
+        const double *c = cod + cell * npt;
+        for (int i = lane; i < npt; i += WAVE) {
+            double v = c[i];
+            s_dom[i] = d[i];
+            s_pdf[i] = exp(v);
+            if (v > best) {
+                best = v;
+                ibest = i;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        double ob = __shfl_xor(best, o, WAVE);
+        int oi = __shfl_xor(ibest, o, WAVE);
+        if (ob > best || (ob == best && oi < ibest)) {
+            best = ob;
+            ibest = oi;
+        }
+    }
+    __syncthreads();
+    // cumulative trapezoid: cdf[0] = 0, cdf[i+1] = cdf[i] + (x[i+1]-x[i]) (y[i+1]+y[i]) / 2
+    double carry = 0.0;
+    const int nseg = npt - 1;
+    if (active) {
+        if (lane == 0) s_cdf[0] = 0.0;
+        for (int base = 0; base < nseg; base += WAVE) {
+            int i = base + lane;
+            double seg = 0.0;
+            if (i < nseg) seg = (s_dom[i + 1] - s_dom[i]) * (s_pdf[i + 1] + s_pdf[i]) / 2.0;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                double u = __shfl_up(seg, o, WAVE);
+                if (lane >= o) seg += u;
+            }
+            double incl = seg + carry;
+            carry = __shfl(incl, WAVE - 1, WAVE);
+            if (i < nseg) s_cdf[i + 1] = incl;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    // normalise, locate the quantiles: searchsorted(cdf, conf) (side='left')
+    const double inv = 1. / carry;
+    const double conf[2] = {c_lo, c_hi};
+    double res[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int idx = npt;
+        for (int i = lane; i < npt; i += WAVE) {
+            if (s_cdf[i] * inv >= conf[q]) {
+                idx = i;
+                break;
+            }
+        }
+#pragma unroll
+        for (int o = WAVE / 2; o > 0; o >>= 1) {
+            int oi = __shfl_xor(idx, o, WAVE);
+            idx = oi < idx ? oi : idx;
+        }
+        if (idx <= 0 || idx >= npt) {
+            res[q] = qnan();
+        } else {
+            double chi = s_cdf[idx] * inv, clo = s_cdf[idx - 1] * inv;
+            double m = (chi - clo) / (s_dom[idx] - s_dom[idx - 1]);
+            res[q] = s_dom[idx - 1] + (conf[q] - clo) / m;
+        }
+    }
+    if (lane == 0) {
+        aguess[cell] = (ibest < npt) ? s_dom[ibest] : qnan();
+        xlo[cell] = res[0];
+        xhi[cell] = res[1];
+    }
+}
+
+// rows 1..5 of get_raw_lightcurve (core.py:1318-1334)
+__global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop, const double *alpha,
+                                       const double *ts, const double *xlo, const double *xhi,
+                                       const double *S, int64_t ncell, double tsmin, double *rows)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    double tmid = 0.5 * (tstart[c] + tstop[c]);
+    double terr = (tmid - tstart[c]) / 86400;
+    double a = alpha[c], t = ts[c];
+    double *r = rows + c * 5;
+    r[0] = terr;
+    if (t <= tsmin) {
+        r[1] = xhi[c];
+        r[2] = 0;
+        r[3] = -1;
+    } else {
+        r[1] = a;
+        r[2] = a - xlo[c];
+        r[3] = xhi[c] - a;
+    }
+    r[4] = t;
+    (void)S;
+}
+
+}   // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+namespace {
+
+// team size from the mean number of photons per cell
+inline int pick_team(int64_t nph, int64_t ncell)
+{
+    double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
+    if (mean <= 8) return 4;
+    if (mean <= 40) return 16;
+    return 64;
+}
+
+inline int check_cells(const void *we, int64_t nph, const void *lo, const void *hi, int64_t ncell,
+                       const char *fn)
+{
+    GODOT_REQUIRE(ncell >= 0 && nph >= 0, GODOT_E_INVALID, "%s: negative size", fn);
+    GODOT_REQUIRE(ncell < ((int64_t)1 << 31) * 4, GODOT_E_UNSUPPORTED, "%s: too many cells", fn);
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(lo && hi, GODOT_E_INVALID, "%s: null cell range pointer", fn);
+    GODOT_REQUIRE(we || nph == 0, GODOT_E_INVALID, "%s: null weights pointer", fn);
+    return GODOT_OK;
+}
+
+#define DISPATCH_TEAM(T_, KERNEL, GRID_ARGS, ...)                                          \
+    do {                                                                                    \
+        switch (T_) {                                                                       \
+        case 4: {                                                                           \
+            dim3 grid((unsigned)ceil_div(ncell, 256 / 4));                                  \
+            hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(256), 0, st, __VA_ARGS__);        \
+        } break;                                                                            \
+        case 16: {                                                                          \
+            dim3 grid((unsigned)ceil_div(ncell, 256 / 16));                                 \
+            hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+        } break;                                                                            \
+        default: {                                                                          \
+            dim3 grid((unsigned)ceil_div(ncell, 256 / 64));                                 \
+            hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+        } break;                                                                            \
+        }                                                                                   \
+    } while (0)
+
+}   // namespace
+
+extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                              const double *S, const double *B, int64_t ncell, const double *guess,
+                              double guess0, const double *beta, double beta0, int swap,
+                              double *alpha, double *ts, int32_t *flags, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_fit");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(S && alpha, GODOT_E_INVALID, "godot_cell_fit: null S or alpha");
+    GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_fit: swap needs B");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts,
+                  flags);
+    GODOT_LAUNCH_CHECK("godot_cell_fit");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_loglike(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                  const double *S, const double *B, int64_t ncell,
+                                  const double *alpha, int swap, double *logl, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_loglike");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(S && alpha && logl, GODOT_E_INVALID, "godot_cell_loglike: null argument");
+    GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_loglike: swap needs B");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_loglike_kernel, 0, p, alpha, logl);
+    GODOT_LAUNCH_CHECK("godot_cell_loglike");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_moments(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                  int64_t ncell, double *wsum, double *w2sum, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_moments");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(wsum && w2sum, GODOT_E_INVALID, "godot_cell_moments: null output");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, 0};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_moments_kernel, 0, p, wsum, w2sum);
+    GODOT_LAUNCH_CHECK("godot_cell_moments");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_beta_max(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                   const double *S, const double *B, int64_t ncell,
+                                   const double *alpha, double alpha0, const double *guess,
+                                   double guess0, int swap, double *beta, double *logl_profile,
+                                   int32_t *flags, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_beta_max");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(S && B && beta, GODOT_E_INVALID, "godot_cell_beta_max: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_beta_kernel, 0, p, alpha, alpha0, guess, guess0, beta,
+                  logl_profile, flags);
+    GODOT_LAUNCH_CHECK("godot_cell_beta_max");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                 const double *S, const double *B, int64_t ncell, const double *aopt,
+                                 double dlogl, int npt, int include_zero, int swap, double *dom,
+                                 double *cod, int32_t *flags, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_logpdf");
+    if (rc) return rc;
+    GODOT_REQUIRE(npt >= 2 && npt <= PQ_MAX_NPT, GODOT_E_UNSUPPORTED,
+                  "godot_cell_logpdf: npt must be in [2, %d]", PQ_MAX_NPT);
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(S && dom && cod, GODOT_E_INVALID, "godot_cell_logpdf: null argument");
+    GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_logpdf: swap needs B");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    size_t smem = (size_t)LP_CH * npt * sizeof(double);
+    dim3 grid((unsigned)ceil_div(ncell, LP_CH));
+    hipLaunchKernelGGL(cell_logpdf_kernel, grid, dim3(256), smem, st, p, aopt, dlogl, npt,
+                       include_zero, dom, cod, flags);
+    GODOT_LAUNCH_CHECK("godot_cell_logpdf");
+    return GODOT_OK;
+}
+
+extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int64_t ncell, int npt,
+                                       double conf_lo, double conf_hi, double *aguess, double *xlo,
+                                       double *xhi, godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_profile_quantiles: negative ncell");
+    GODOT_REQUIRE(npt >= 2 && npt <= PQ_MAX_NPT, GODOT_E_UNSUPPORTED,
+                  "godot_profile_quantiles: npt must be in [2, %d]", PQ_MAX_NPT);
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(dom && cod && aguess && xlo && xhi, GODOT_E_INVALID,
+                  "godot_profile_quantiles: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    size_t smem = (size_t)4 * 3 * npt * sizeof(double);
+    dim3 grid((unsigned)ceil_div(ncell, 4));
+    hipLaunchKernelGGL(profile_quantiles_kernel, grid, dim3(256), smem, st, dom, cod, ncell, npt,
+                       conf_lo, conf_hi, aguess, xlo, xhi);
+    GODOT_LAUNCH_CHECK("godot_profile_quantiles");
+    return GODOT_OK;
+}
+
+extern "C" int godot_lightcurve_rows(const double *tstart, const double *tstop, const double *alpha,
+                                     const double *ts, const double *xlo, const double *xhi,
+                                     const double *S, int64_t ncell, double tsmin, double *rows,
+                                     godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_lightcurve_rows: negative ncell");
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(tstart && tstop && alpha && ts && xlo && xhi && rows, GODOT_E_INVALID,
+                  "godot_lightcurve_rows: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lightcurve_rows_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st,
+                       tstart, tstop, alpha, ts, xlo, xhi, S, ncell, tsmin, rows);
+    GODOT_LAUNCH_CHECK("godot_lightcurve_rows");
+    return GODOT_OK;
+}

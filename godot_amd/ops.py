@@ -1,0 +1,165 @@
+"""Tensor-level wrappers over the C ABI.
+
+Inputs and outputs are torch tensors on a ROCm device (torch is used for
+device memory and streams only).  Every function enqueues work on torch's
+current stream of the tensors' device and returns without synchronising.
+"""
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+I64 = torch.int64
+I32 = torch.int32
+
+
+def _dev_check(t, dtype, name):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise ValueError('%s must live on the GPU (got %s); there is no CPU path' % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('%s must have dtype %s (got %s)' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class CellRanges(object):
+    """Device view of many cells: weights + per-cell photon ranges + S, B."""
+
+    def __init__(self, we, lo, hi, S, B):
+        _dev_check(we, F64, 'we')
+        _dev_check(lo, I64, 'lo')
+        _dev_check(hi, I64, 'hi')
+        _dev_check(S, F64, 'S')
+        _dev_check(B, F64, 'B')
+        n = lo.numel()
+        if hi.numel() != n or S.numel() != n or (B is not None and B.numel() != n):
+            raise ValueError('lo, hi, S, B must have one entry per cell')
+        self.we, self.lo, self.hi, self.S, self.B = we, lo, hi, S, B
+        self.ncell = n
+        self.nph = we.numel()
+        self.device = we.device
+
+    @classmethod
+    def from_offsets(cls, we, offsets, S, B):
+        _dev_check(offsets, I64, 'offsets')
+        return cls(we, offsets[:-1], offsets[1:], S, B)
+
+    def _head(self):
+        return (_p(self.we), self.nph, _p(self.lo), _p(self.hi))
+
+
+def _per_cell(x, n, dev, name):
+    """Scalar -> (None, scalar); tensor -> (tensor, 0.0)."""
+    if x is None:
+        return None, 0.0
+    if isinstance(x, torch.Tensor):
+        _dev_check(x, F64, name)
+        if x.numel() != n:
+            raise ValueError('%s must have one entry per cell' % name)
+        return x, 0.0
+    return None, float(x)
+
+
+def cell_fit(cr, guess=1.0, beta=1.0, swap=False, want_ts=True):
+    n, dev = cr.ncell, cr.device
+    gt, g0 = _per_cell(guess, n, dev, 'guess')
+    bt, b0 = _per_cell(beta, n, dev, 'beta')
+    alpha = torch.empty(n, dtype=F64, device=dev)
+    ts = torch.empty(n, dtype=F64, device=dev) if want_ts else None
+    flags = torch.empty(n, dtype=I32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_fit', *cr._head(), _p(cr.S), _p(cr.B), n, _p(gt), g0, _p(bt), b0,
+                  int(bool(swap)), _p(alpha), _p(ts), _p(flags), _stream(dev))
+    return alpha, ts, flags
+
+
+def cell_loglike(cr, alpha, swap=False):
+    n, dev = cr.ncell, cr.device
+    _dev_check(alpha, F64, 'alpha')
+    if alpha.numel() != n:
+        raise ValueError('alpha must have one entry per cell')
+    out = torch.empty(n, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_loglike', *cr._head(), _p(cr.S), _p(cr.B), n, _p(alpha),
+                  int(bool(swap)), _p(out), _stream(dev))
+    return out
+
+
+def cell_logpdf(cr, aopt=None, dlogl=20., npt=100, include_zero=False, swap=False):
+    n, dev = cr.ncell, cr.device
+    if aopt is not None:
+        _dev_check(aopt, F64, 'aopt')
+        if aopt.numel() != n:
+            raise ValueError('aopt must have one entry per cell')
+    dom = torch.empty((n, npt), dtype=F64, device=dev)
+    cod = torch.empty((n, npt), dtype=F64, device=dev)
+    flags = torch.empty(n, dtype=I32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_logpdf', *cr._head(), _p(cr.S), _p(cr.B), n, _p(aopt), float(dlogl),
+                  int(npt), int(bool(include_zero)), int(bool(swap)), _p(dom), _p(cod), _p(flags),
+                  _stream(dev))
+    return dom, cod, flags
+
+
+def profile_quantiles(dom, cod, conf_lo, conf_hi):
+    _dev_check(dom, F64, 'dom')
+    _dev_check(cod, F64, 'cod')
+    n, npt = dom.shape
+    dev = dom.device
+    ag = torch.empty(n, dtype=F64, device=dev)
+    xlo = torch.empty(n, dtype=F64, device=dev)
+    xhi = torch.empty(n, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_profile_quantiles', _p(dom), _p(cod), n, npt, float(conf_lo),
+                  float(conf_hi), _p(ag), _p(xlo), _p(xhi), _stream(dev))
+    return ag, xlo, xhi
+
+
+def lightcurve_rows(tstart, tstop, alpha, ts, xlo, xhi, S, tsmin):
+    n, dev = alpha.numel(), alpha.device
+    for t, nm in ((tstart, 'tstart'), (tstop, 'tstop'), (alpha, 'alpha'), (ts, 'ts'), (xlo, 'xlo'),
+                  (xhi, 'xhi'), (S, 'S')):
+        _dev_check(t, F64, nm)
+    rows = torch.empty((n, 5), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_lightcurve_rows', _p(tstart), _p(tstop), _p(alpha), _p(ts), _p(xlo),
+                  _p(xhi), _p(S), n, float(tsmin), _p(rows), _stream(dev))
+    return rows
+
+
+def cell_beta_max(cr, alpha, guess=1.0, swap=False, want_logl=True):
+    n, dev = cr.ncell, cr.device
+    at, a0 = _per_cell(alpha, n, dev, 'alpha')
+    gt, g0 = _per_cell(guess, n, dev, 'guess')
+    beta = torch.empty(n, dtype=F64, device=dev)
+    lp = torch.empty(n, dtype=F64, device=dev) if want_logl else None
+    flags = torch.empty(n, dtype=I32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_beta_max', *cr._head(), _p(cr.S), _p(cr.B), n, _p(at), a0, _p(gt), g0,
+                  int(bool(swap)), _p(beta), _p(lp), _p(flags), _stream(dev))
+    return beta, lp, flags
+
+
+def cell_moments(we, lo, hi):
+    _dev_check(we, F64, 'we')
+    _dev_check(lo, I64, 'lo')
+    _dev_check(hi, I64, 'hi')
+    n, dev = lo.numel(), we.device
+    w1 = torch.empty(n, dtype=F64, device=dev)
+    w2 = torch.empty(n, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_moments', _p(we), we.numel(), _p(lo), _p(hi), n, _p(w1), _p(w2),
+                  _stream(dev))
+    return w1, w2

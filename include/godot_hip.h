@@ -1,0 +1,244 @@
+/*
+ * godot_hip.h -- C ABI of libgodot_hip.so: MI355X (gfx950) kernels for the
+ * weighted-photon likelihood / periodogram hot path of kerrm/godot.
+ *
+ * The reference has no FFI of its own: the boundary it exposes for this path
+ * is the Python API of its core.py.  Each entry point below replaces the
+ * arithmetic of the reference function cited next to it (file:line relative to
+ * the reference checkout); the Python classes in godot_amd/core.py keep the
+ * reference's names and signatures and forward to these functions via ctypes.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless its name ends in _host.
+ *   - The caller allocates every input, output and workspace; the library
+ *     never allocates, frees or keeps a pointer past the call.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and is asynchronous with respect to the host.
+ *   - Return value: 0 on success, a negative GODOT_E_* code on failure;
+ *     godot_last_error() returns a thread-local message for the last failure.
+ *   - Photons of cell c are we[lo[c] .. hi[c]-1].  For a CSR layout pass
+ *     lo = offsets and hi = offsets + 1.  `nph` is the number of elements of
+ *     `we`; a cell whose range is not inside [0, nph] is not read: its outputs
+ *     are NaN and it gets GODOT_F_FAILED.
+ *   - Floating point is IEEE binary64 throughout; indices are int64_t.
+ */
+#ifndef GODOT_HIP_H
+#define GODOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GODOT_OK            0
+#define GODOT_E_INVALID    -1   /* bad argument (null pointer, negative size ...) */
+#define GODOT_E_WORKSPACE  -2   /* workspace too small */
+#define GODOT_E_LAUNCH     -3   /* HIP reported a launch/runtime error */
+#define GODOT_E_UNSUPPORTED -4  /* size outside what the kernels accept */
+
+/* per-cell status bits written to `flags` outputs */
+#define GODOT_F_AT_ZERO     0x01  /* maximum at the alpha = 0 boundary         */
+#define GODOT_F_DEPTH_MASK  0x06  /* restart depth (0..3) << 1                 */
+#define GODOT_F_BRENT       0x08  /* bracketing root finder was used           */
+#define GODOT_F_FAILED      0x10  /* no bracket / no convergence: output NaN   */
+#define GODOT_F_RECENTRED   0x20  /* profile grid was re-centred at least once */
+
+typedef void *godot_stream_t;
+
+const char *godot_last_error(void);
+int godot_version(void);
+
+/* ---- cell likelihood: CellLogLikelihood, core.py:329-1044 ----------------- */
+
+/* Maximum-likelihood flux multiplier and TS of every cell with the background
+ * level fixed.  Replaces CellLogLikelihood.get_max(guess, beta) (core.py:632-691,
+ * incl. its restart rule and the get_max_numerical fallback, core.py:693-739)
+ * followed by get_ts(aopt) (core.py:982-994).
+ *   S[c], B[c]   expected source / background counts of the cell (Cell.exp and
+ *                Cell.exp / Cell.SonB, core.py:344-345)
+ *   guess, beta  per-cell start values, or NULL to use guess0 / beta0 for all
+ *   swap         non-zero: exchange source and background (core.py:346-348)
+ *   alpha, ts    outputs [ncell]; ts may be NULL
+ *   flags        output [ncell] of GODOT_F_* bits; may be NULL               */
+int godot_cell_fit(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                   const double *S, const double *B, int64_t ncell,
+                   const double *guess, double guess0,
+                   const double *beta, double beta0, int swap,
+                   double *alpha, double *ts, int32_t *flags,
+                   godot_stream_t stream);
+
+/* logL(alpha_c) of every cell: CellLogLikelihood.log_likelihood
+ * (core.py:353-364).  alpha is per cell.                                      */
+int godot_cell_loglike(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                       const double *S, const double *B, int64_t ncell,
+                       const double *alpha, int swap, double *logl,
+                       godot_stream_t stream);
+
+/* Adaptive-support log-likelihood profile of every cell: get_logpdf
+ * (core.py:851-932) as driven by CellsLogLikelihood.__init__
+ * (core.py:1087-1095: npt = 200, dlogl = 30).
+ *   aopt    per-cell maximum to centre on, or NULL to run get_max() first
+ *   dom,cod outputs [ncell][npt], row-major                                   */
+int godot_cell_logpdf(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                      const double *S, const double *B, int64_t ncell,
+                      const double *aopt, double dlogl, int npt,
+                      int include_zero, int swap,
+                      double *dom, double *cod, int32_t *flags,
+                      godot_stream_t stream);
+
+/* Post-processing of the cached profiles: CellsLogLikelihood.get_flux
+ * (core.py:1229, 1247-1256).  aguess = dom[argmax cod]; xlo/xhi = quantiles
+ * conf_lo/conf_hi of the normalised pdf (trapezoid cdf + linear interpolation). */
+int godot_profile_quantiles(const double *dom, const double *cod,
+                            int64_t ncell, int npt,
+                            double conf_lo, double conf_hi,
+                            double *aguess, double *xlo, double *xhi,
+                            godot_stream_t stream);
+
+/* Assemble light-curve rows 1..5 of get_raw_lightcurve (core.py:1329-1334):
+ * out[c] = {terr_days, alpha|UL, err_lo|0, err_hi|-1, TS}; column 0 (MJD of the
+ * cell mid-time) is formed on the host in extended precision as the reference
+ * does (core.py:24-26).                                                       */
+int godot_lightcurve_rows(const double *tstart, const double *tstop,
+                          const double *alpha, const double *ts,
+                          const double *xlo, const double *xhi,
+                          const double *S, int64_t ncell, double tsmin,
+                          double *rows /* [ncell][5] */,
+                          godot_stream_t stream);
+
+/* Background level maximising logL at fixed alpha: get_beta_max
+ * (core.py:741-823) and the profile likelihood built on it
+ * (log_profile_likelihood, core.py:391-406).  alpha per cell or alpha0.
+ * logl_profile may be NULL.  A cell where the reference would raise
+ * ValueError (core.py:818) gets NaN and GODOT_F_FAILED.                       */
+int godot_cell_beta_max(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                        const double *S, const double *B, int64_t ncell,
+                        const double *alpha, double alpha0,
+                        const double *guess, double guess0, int swap,
+                        double *beta, double *logl_profile, int32_t *flags,
+                        godot_stream_t stream);
+
+/* ---- binning: Data.get_exposure / Data.get_cells, core.py:1792-1843, 2063-2206 */
+
+/* Bytes of workspace godot_exposure_at needs for a table of n_ft2 rows.       */
+size_t godot_exposure_workspace_bytes(int64_t n_ft2);
+
+/* Exposure, source-scaled exposure, background-scaled exposure and dead time
+ * at the query times (cumulative != 0) or between consecutive query times
+ * (cumulative == 0: outputs have n_t - 1 entries).  Replaces
+ * Data.get_exposure (core.py:1806-1841).  out_dead may be NULL.               */
+int godot_exposure_at(const double *tstart, const double *tstop,
+                      const double *exposure, const double *livetime,
+                      int64_t n_ft2, double s_over_e, double b_over_e,
+                      const double *times, int64_t n_t, int cumulative,
+                      double *out_exp, double *out_sexp, double *out_bexp,
+                      double *out_dead, void *workspace, size_t workspace_bytes,
+                      godot_stream_t stream);
+
+/* Photon range of every cell for time-sorted photons: the integer result of
+ * searchsorted(ti,[starts[0],stops[-1]]) + searchsorted(stops,times) +
+ * bincount (core.py:2097-2099, 2159-2161): photon i belongs to cell c iff
+ * stops[c-1] < ti[i] <= stops[c], restricted to start0 <= ti[i] < stops[-1].
+ * lo/hi index the ORIGINAL ti/we arrays; counts[c] = hi[c] - lo[c].           */
+int godot_bin_photons(const double *ti, int64_t nph, double start0,
+                      const double *stops, int64_t ncell,
+                      int64_t *lo, int64_t *hi, int64_t *counts,
+                      godot_stream_t stream);
+
+/* Per-cell moments sum(w), sum(w^2) (core.py:2178-2183).                      */
+int godot_cell_moments(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                       int64_t ncell, double *wsum, double *w2sum,
+                       godot_stream_t stream);
+
+/* Indices of the cells with exp > threshold in ascending order (the
+ * trim_zero_exposure mask, core.py:2110-2122).  n_keep is a device int64.
+ * workspace: godot_select_workspace_bytes(ncell).                             */
+size_t godot_select_workspace_bytes(int64_t ncell);
+int godot_select_cells(const double *exp, int64_t ncell, double threshold,
+                       int64_t *keep_idx, int64_t *n_keep,
+                       void *workspace, size_t workspace_bytes,
+                       godot_stream_t stream);
+int godot_gather_f64(const double *src, const int64_t *idx, int64_t n,
+                     double *dst, godot_stream_t stream);
+int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n,
+                     int64_t *dst, godot_stream_t stream);
+
+/* ---- power spectra: core.py:2598-2782 -------------------------------------- */
+
+/* Real-to-complex forward DFT of x[0..n-1] zero-padded to length l (l a power
+ * of two >= 2): out[k] = sum_j x[j] exp(-2 pi i j k / l), k = 0..l/2, stored
+ * as interleaved (re, im).  Stands in for numpy.fft.rfft at core.py:2683-2701.
+ * workspace: godot_rfft_workspace_bytes(l).                                   */
+size_t godot_rfft_workspace_bytes(int64_t l);
+int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out,
+                   void *workspace, size_t workspace_bytes,
+                   godot_stream_t stream);
+
+/* power_spectrum_fft (core.py:2635-2741) from the six per-bin series; the
+ * scalar options (tweak_exp, exposure_correction, exp_only, maxN) are applied
+ * by the caller to the series before the call.  Outputs have l/4+1 entries.
+ * If amps != NULL it receives the 8 amplitude arrays of get_amps=True
+ * (alpha_cos, alpha_sin, beta_cos, beta_sin, alpha_cos0, alpha_sin0,
+ * beta_cos0, beta_sin0), [8][l/4+1].
+ * workspace: godot_power_spectrum_workspace_bytes(l).                         */
+size_t godot_power_spectrum_workspace_bytes(int64_t l);
+int godot_power_spectrum_fft(const double *W, const double *WW, const double *S,
+                             const double *Wb, const double *WbWb,
+                             const double *B, int64_t n, int64_t l,
+                             double *p0, double *p1, double *pb, double *amps,
+                             void *workspace, size_t workspace_bytes,
+                             godot_stream_t stream);
+
+/* power_spectrum_simple (core.py:2758-2782): l = n must be a power of two.
+ * moments (may be NULL) receives (cos, sin, cc, ss), [4][l/4+1].              */
+int godot_power_spectrum_simple(const double *W, const double *WW,
+                                const double *S, int64_t n,
+                                double *dlogl, double *moments,
+                                void *workspace, size_t workspace_bytes,
+                                godot_stream_t stream);
+
+/* ---- direct trig sums: core.py:2426-2596 ----------------------------------- */
+
+/* power_spectrum_dft (core.py:2540-2596): per-cell phase from the 1000-entry
+ * cos/sin table, photon moments through the CSR layout.                       */
+int godot_trigsum_cells(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                        const double *exp, const double *tmid, int64_t ncell,
+                        const double *freqs, int64_t nfreq, int unweighted,
+                        double exp_scale, double *power,
+                        godot_stream_t stream);
+
+/* fit_harmonics (core.py:2426-2488) at nfreq frequencies: out[f] =
+ * {camp, samp, ts}.                                                           */
+int godot_fit_harmonics(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                        const double *exp, const double *tmid, int64_t ncell,
+                        const double *freqs, int64_t nfreq,
+                        double *out /* [nfreq][3] */, godot_stream_t stream);
+
+/* Weighted Z^2_m on the uniform grid f_j = f0 + (j0 + j) df, j = 0..nf-1:
+ *   Z2m = 2 / sum(w^2) * sum_{k=1..m} [(sum_i w_i cos 2 pi k f t_i)^2 +
+ *                                      (sum_i w_i sin 2 pi k f t_i)^2].
+ * No counterpart in the reference (it holds no Z^2_m / H-test routine; the
+ * statistic is the photon-phase limit of fit_harmonics, core.py:2481).
+ * t is relative to any epoch the caller chooses.  1 <= m <= 20.
+ *   z2   output [nf] (Z^2_m), may be NULL
+ *   h    output [nf] (H = max_k (Z^2_k - 4k + 4), k <= m), may be NULL
+ * workspace: godot_z2m_workspace_bytes(nph).                                  */
+size_t godot_z2m_workspace_bytes(int64_t nph);
+int godot_z2m(const double *t, const double *w, int64_t nph,
+              double f0, double df, int64_t j0, int64_t nf, int m,
+              double *z2, double *h, void *workspace, size_t workspace_bytes,
+              godot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GODOT_HIP_H */
