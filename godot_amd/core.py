@@ -1,0 +1,567 @@
+"""Host-side mirror of the reference's analysis API (its core.py) for the
+likelihood / periodogram hot path.
+
+Class and function names, argument order, defaults and error behaviour follow
+the reference so that its callers can switch over; the arithmetic runs in the
+HIP library (godot_amd.ops -> libgodot_hip.so).  There is no CPU path: every
+compute method needs a ROCm device.
+
+Device layout.  Many cells are held as one ``CellBatch``: photon weights (and
+times) of all cells in one device array plus per-cell ranges ``lo``/``hi``
+and per-cell ``starts, stops, sexp, bexp``.  ``Cell`` objects (the
+reference's per-cell value type, core.py:161-187) are materialised from a
+batch only on request.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+__all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries',
+           'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
+           'met2mjd', 'mjd2met', 'infer_met']
+
+MJDREF = 51910 + 7.428703703703703e-4
+F64 = torch.float64
+I64 = torch.int64
+
+
+def met2mjd(times, mjdref=MJDREF):
+    """Reference core.py:24-26 (extended precision on the host)."""
+    return np.asarray(times, dtype=np.longdouble) * (1. / 86400) + mjdref
+
+
+def mjd2met(times, mjdref=MJDREF):
+    """Reference core.py:28-30."""
+    return (np.asarray(times, dtype=np.longdouble) - mjdref) * 86400
+
+
+def infer_met(time):
+    """Reference core.py:32-35."""
+    if time < 100000:
+        return mjd2met(time)
+    return time
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('godot_amd needs a ROCm GPU: no device is visible and there is no '
+                           'CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _to_dev(x, dev, dtype=F64):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype={F64: np.float64,
+                                                                       I64: np.int64}[dtype])).to(dev)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+# ---------------------------------------------------------------------------
+# Cell value types (reference core.py:161-210)
+# ---------------------------------------------------------------------------
+class Cell(object):
+    """A start/stop time, the exposure and the photons inside (host arrays)."""
+
+    def __init__(self, tstart, tstop, exposure, photon_times, photon_weights,
+                 source_to_background_ratio):
+        self.tstart = tstart
+        self.tstop = tstop
+        self.exp = exposure
+        self.ti = np.atleast_1d(photon_times)
+        self.we = np.atleast_1d(photon_weights)
+        self.SonB = source_to_background_ratio
+        self._alpha = 1
+        self._beta = 1
+
+    def sanity_check(self):
+        if self.exp == 0:
+            assert(len(self.ti) == 0)
+        assert(len(self.ti) == len(self.we))
+        assert(np.all(self.ti >= self.tstart))
+        assert(np.all(self.ti < self.tstop))
+
+    def get_tmid(self):
+        return 0.5 * (self.tstart + self.tstop)
+
+
+class PhaseCell(Cell):
+
+    def copy(self, phase_offset=0):
+        return PhaseCell(self.tstart + phase_offset, self.tstop + phase_offset,
+                         self.exp, self.ti, self.we, self.SonB)
+
+
+def cell_from_cells(cells):
+    """One Cell spanning several (reference core.py:200-210)."""
+    cells = sorted(cells, key=lambda c: c.tstart)
+    we = np.concatenate([c.we for c in cells])
+    ti = np.concatenate([c.ti for c in cells])
+    exp = np.asarray([c.exp for c in cells]).sum()
+    bexp = np.asarray([c.exp / c.SonB for c in cells]).sum()
+    return Cell(cells[0].tstart, cells[-1].tstop, exp, ti, we, exp / bexp)
+
+
+class CellBatch(object):
+    """Device-resident list of cells; behaves like the list of Cell objects
+    the reference's Data.get_cells returns (len, indexing, iteration)."""
+
+    def __init__(self, we, ti, lo, hi, starts, stops, sexp, bexp):
+        self.we, self.ti, self.lo, self.hi = we, ti, lo, hi
+        self.starts, self.stops, self.sexp, self.bexp = starts, stops, sexp, bexp
+        self.device = we.device
+        self._host = None
+
+    @classmethod
+    def from_cells(cls, cells, device=None):
+        dev = device or default_device()
+        counts = np.array([len(c.we) for c in cells], dtype=np.int64)
+        off = np.append(0, np.cumsum(counts)).astype(np.int64)
+        cat = (lambda xs: np.concatenate(xs) if len(xs) else np.empty(0))
+        we = cat([np.asarray(c.we, dtype=np.float64) for c in cells])
+        ti = cat([np.asarray(c.ti, dtype=np.float64) for c in cells])
+        # the weight scales of Cell._alpha/_beta (reference core.py:341-345)
+        if any((c._alpha != 1) or (c._beta != 1) for c in cells):
+            a = np.repeat([c._alpha for c in cells], counts)
+            b = np.repeat([c._beta for c in cells], counts)
+            we = we * a / (we * a + b * (1 - we))
+        sexp = np.array([c.exp * c._alpha for c in cells], dtype=np.float64)
+        bexp = np.array([c.exp / c.SonB * c._beta for c in cells], dtype=np.float64)
+        offd = _to_dev(off, dev, I64)
+        return cls(_to_dev(we, dev), _to_dev(ti, dev), offd[:-1], offd[1:],
+                   _to_dev([c.tstart for c in cells], dev), _to_dev([c.tstop for c in cells], dev),
+                   _to_dev(sexp, dev), _to_dev(bexp, dev))
+
+    def ranges(self):
+        return ops.CellRanges(self.we, self.lo.contiguous(), self.hi.contiguous(), self.sexp,
+                              self.bexp)
+
+    def __len__(self):
+        return self.lo.numel()
+
+    def _hostcopy(self):
+        if self._host is None:
+            self._host = dict(lo=_np(self.lo), hi=_np(self.hi), starts=_np(self.starts),
+                              stops=_np(self.stops), sexp=_np(self.sexp), bexp=_np(self.bexp))
+        return self._host
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return CellBatch(self.we, self.ti, self.lo[i].contiguous(), self.hi[i].contiguous(),
+                             self.starts[i].contiguous(), self.stops[i].contiguous(),
+                             self.sexp[i].contiguous(), self.bexp[i].contiguous())
+        h = self._hostcopy()
+        n = len(h['lo'])
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError('cell index out of range')
+        l, u = int(h['lo'][i]), int(h['hi'][i])
+        return Cell(h['starts'][i], h['stops'][i], h['sexp'][i], _np(self.ti[l:u]),
+                    _np(self.we[l:u]), h['sexp'][i] / h['bexp'][i])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+def _as_batch(cells, device=None):
+    if isinstance(cells, CellBatch):
+        return cells
+    return CellBatch.from_cells(list(cells), device=device)
+
+
+# ---------------------------------------------------------------------------
+# CellTimeSeries (reference core.py:212-327)
+# ---------------------------------------------------------------------------
+class CellTimeSeries(object):
+    """Uniform-bin moments of the photon weights.  Arrays may be numpy arrays
+    or device tensors; like the reference the constructor zeroes, IN PLACE,
+    every moment of the bins with exp <= minimum_exposure."""
+
+    _KEYS = ['starts', 'stops', 'exp', 'sexp', 'bexp', 'counts', 'weights', 'weights2',
+             'deadtime']
+
+    def __init__(self, starts, stops, exp, sexp, bexp, counts, weights, weights2, deadtime,
+                 alt_starts=None, alt_stops=None, timesys='barycenter', minimum_exposure=3e4):
+        self.starts = starts
+        self.stops = stops
+        self.exp = exp
+        self.sexp = sexp
+        self.bexp = bexp
+        self.counts = counts
+        self.weights = weights
+        self.weights2 = weights2
+        self.deadtime = deadtime
+        self.alt_starts = alt_starts
+        self.alt_stops = alt_stops
+        self.timesys = timesys
+        self.minimum_exposure = minimum_exposure
+        mask = ~(exp > minimum_exposure)
+        self._zero_weight(mask)
+
+    def _zero_weight(self, mask):
+        for k in ('exp', 'sexp', 'bexp', 'counts', 'weights', 'weights2'):
+            getattr(self, k)[mask] = 0
+
+    def save(self, fname, compress=True):
+        keys = list(self._KEYS)
+        if self.alt_starts is not None:
+            keys += ['alt_starts']
+        if self.alt_stops is not None:
+            keys += ['alt_stops']
+        d = dict((k, _np(getattr(self, k))) for k in keys)
+        d['metadata'] = [str(self.minimum_exposure), self.timesys]
+        (np.savez_compressed if compress else np.savez)(fname, **d)
+
+    @staticmethod
+    def load(fname, device=None):
+        with np.load(fname) as q:
+            minimum_exposure = float(q['metadata'][0])
+            timesys = str(q['metadata'][1])
+            alt_starts = q['alt_starts'] if 'alt_starts' in q.files else None
+            alt_stops = q['alt_stops'] if 'alt_stops' in q.files else None
+            args = [q[k] for k in CellTimeSeries._KEYS]
+        if device is not None:
+            args = [_to_dev(a, device, I64 if a.dtype.kind in 'iu' else F64) for a in args]
+        return CellTimeSeries(*args, alt_starts=alt_starts, alt_stops=alt_stops,
+                              timesys=timesys, minimum_exposure=minimum_exposure)
+
+    def tsamp(self):
+        return float(self.stops[0] - self.starts[0])
+
+    def ps_nbin(self):
+        return len(self.starts) // 4 + 1
+
+    def tspan(self):
+        return float(self.stops[-1] - self.starts[0])
+
+    def get_topo_bins(self):
+        if self.timesys == 'barycenter':
+            if self.alt_starts is None:
+                raise Exception('Do not have topocentric bins.')
+            return self.alt_starts, self.alt_stops
+        return self.starts, self.stops
+
+    def get_bary_bins(self):
+        if self.timesys != 'barycenter':
+            if self.alt_starts is None:
+                raise Exception('Do not have barycentric bins.')
+            return self.alt_starts, self.alt_stops
+        return self.starts, self.stops
+
+    def zero_weight(self, tstart, tstop):
+        tstart = float(infer_met(tstart))
+        tstop = float(infer_met(tstop))
+        mask = (self.starts >= tstart) & (self.stops <= tstop)
+        self._zero_weight(mask)
+
+
+# ---------------------------------------------------------------------------
+# Likelihood of one cell / of many cells (reference core.py:329-1044, 1047-1336)
+# ---------------------------------------------------------------------------
+def _scalar(t):
+    return float(t.cpu().numpy().ravel()[0])
+
+
+class CellLogLikelihood(object):
+    """Single-cell view of the batched kernels (a batch of one cell)."""
+
+    def __init__(self, cell, swap=False, device=None):
+        self.cell = cell
+        self.ti = cell.ti
+        a, b, w = cell._alpha, cell._beta, np.asarray(cell.we, dtype=np.float64)
+        self.we = w * a / (w * a + b * (1 - w))
+        self.iwe = 1 - self.we
+        self.S = cell.exp * cell._alpha
+        self.B = cell.exp / cell.SonB * cell._beta
+        self._swap = bool(swap)
+        if swap:
+            self.we, self.iwe = self.iwe, self.we
+            self.S, self.B = self.B, self.S
+        dev = device or default_device()
+        # the kernels take the un-swapped layout plus the swap switch
+        wd = _to_dev(self.iwe if swap else self.we, dev)
+        off = torch.tensor([0, wd.numel()], dtype=I64, device=dev)
+        S0, B0 = (self.B, self.S) if swap else (self.S, self.B)
+        self._cr = ops.CellRanges.from_offsets(
+            wd, off, torch.tensor([S0], dtype=F64, device=dev),
+            torch.tensor([B0], dtype=F64, device=dev))
+        self._dev = dev
+
+    def _t(self, x):
+        return torch.tensor([float(x)], dtype=F64, device=self._dev)
+
+    def log_likelihood(self, alpha):
+        return _scalar(ops.cell_loglike(self._cr, self._t(alpha), swap=self._swap))
+
+    def get_max(self, guess=1, beta=1, profile_background=False):
+        if profile_background:
+            raise NotImplementedError('joint (alpha, beta) fit is not built yet')
+        a, _, fl = ops.cell_fit(self._cr, guess=float(guess), beta=float(beta), swap=self._swap,
+                                want_ts=False)
+        a = _scalar(a)
+        if np.isnan(a):
+            raise ValueError('f(a) and f(b) must have different signs')
+        # the reference returns the integer 0 on the boundary branch
+        return 0 if (int(fl.cpu()[0]) & 1) else a
+
+    def get_ts(self, aopt=None, profile_background=False):
+        if profile_background:
+            raise NotImplementedError('profile-background TS is not built yet')
+        if self.S == 0:
+            return 0
+        g = 1.0 if aopt is None else float(aopt)
+        if aopt is None:
+            a, ts, _ = ops.cell_fit(self._cr, swap=self._swap)
+            return _scalar(ts)
+        if aopt == 0:
+            return 0
+        l1 = self.log_likelihood(g)
+        l0 = self.log_likelihood(0.0)
+        return 2 * (l1 - l0)
+
+    def get_logpdf(self, aopt=None, dlogl=20, npt=100, include_zero=False,
+                   profile_background=False):
+        if profile_background:
+            raise NotImplementedError('profile-background log pdf is not built yet')
+        at = None if aopt is None else self._t(aopt)
+        dom, cod, fl = ops.cell_logpdf(self._cr, aopt=at, dlogl=dlogl, npt=npt,
+                                       include_zero=include_zero, swap=self._swap)
+        return _np(dom[0]), _np(cod[0])
+
+    def get_pdf(self, aopt=None, dlogl=20, npt=100, profile_background=False):
+        from scipy.integrate import simpson
+        dom, cod = self.get_logpdf(aopt=aopt, dlogl=dlogl, npt=npt,
+                                   profile_background=profile_background)
+        np.exp(cod, out=cod)
+        return dom, cod * (1. / simpson(cod, x=dom))
+
+    def get_beta_max(self, alpha, guess=1):
+        b, _, fl = ops.cell_beta_max(self._cr, float(alpha), guess=float(guess), swap=self._swap,
+                                     want_logl=False)
+        if int(fl.cpu()[0]) & 0x10:
+            raise ValueError('Did not converge for alpha=%.5f!' % alpha)
+        return _scalar(b)
+
+    def log_profile_likelihood(self, alpha, beta_guess=1):
+        b, lp, fl = ops.cell_beta_max(self._cr, float(alpha), guess=float(beta_guess),
+                                      swap=self._swap)
+        if int(fl.cpu()[0]) & 0x10:
+            raise ValueError('Did not converge for alpha=%.5f!' % alpha)
+        self._last_beta = _scalar(b) - 1
+        return _scalar(lp)
+
+
+class CellsLogLikelihood(object):
+    """Batch driver: cached (ncell, 200) log-likelihood profiles, fluxes and
+    the raw light curve (reference core.py:1070-1098, 1227-1336)."""
+
+    def __init__(self, cells, profile_background=False, swap=False, reverse=False, device=None):
+        if profile_background:
+            raise NotImplementedError('profile_background=True is not built yet')
+        batch = _as_batch(cells, device=device)
+        if reverse:
+            batch = batch[::-1] if not isinstance(batch, CellBatch) else CellBatch(
+                batch.we, batch.ti, batch.lo.flip(0).contiguous(), batch.hi.flip(0).contiguous(),
+                batch.starts.flip(0).contiguous(), batch.stops.flip(0).contiguous(),
+                batch.sexp.flip(0).contiguous(), batch.bexp.flip(0).contiguous())
+        self.cells = batch
+        self._swap = bool(swap)
+        self.profile_background = False
+        self._cr = batch.ranges()
+        self._dom_d, self._cod_d, self._flags = ops.cell_logpdf(self._cr, dlogl=30, npt=200,
+                                                                swap=self._swap)
+        self._dom_h = self._cod_h = None
+        self.fitness_vals = None
+
+    @property
+    def _dom(self):
+        if self._dom_h is None:
+            self._dom_h = _np(self._dom_d)
+        return self._dom_h
+
+    @property
+    def _cod(self):
+        if self._cod_h is None:
+            self._cod_h = _np(self._cod_d)
+        return self._cod_h
+
+    @property
+    def clls(self):
+        return [CellLogLikelihood(c, swap=self._swap, device=self.cells.device)
+                for c in self.cells]
+
+    def __len__(self):
+        return len(self.cells)
+
+    def get_flux_all(self, conf=[0.05, 0.95]):
+        """(aopt, ts, xlo, xhi) device tensors for every cell."""
+        ag, xlo, xhi = ops.profile_quantiles(self._dom_d, self._cod_d, conf[0], conf[1])
+        aopt, ts, _ = ops.cell_fit(self._cr, guess=ag, beta=1.0, swap=self._swap)
+        return aopt, ts, xlo, xhi
+
+    def get_flux(self, idx, conf=[0.05, 0.95]):
+        sub = CellsLogLikelihood.__new__(CellsLogLikelihood)
+        sub._cr = ops.CellRanges(self._cr.we, self._cr.lo[idx:idx + 1].contiguous(),
+                                 self._cr.hi[idx:idx + 1].contiguous(),
+                                 self._cr.S[idx:idx + 1].contiguous(),
+                                 self._cr.B[idx:idx + 1].contiguous())
+        sub._dom_d = self._dom_d[idx:idx + 1].contiguous()
+        sub._cod_d = self._cod_d[idx:idx + 1].contiguous()
+        sub._swap = self._swap
+        aopt, ts, xlo, xhi = sub.get_flux_all(conf)
+        return _scalar(aopt), _scalar(ts), np.array([_scalar(xlo), _scalar(xhi)])
+
+    def log_likelihood(self, alpha, slow_but_sure=False):
+        if len(alpha) != len(self.cells):
+            raise ValueError('Must provide a value of alpha for all cells!')
+        if not slow_but_sure:
+            dom, cod = self._dom, self._cod
+            alpha_h = _np(alpha)
+            if np.all((alpha_h >= dom[:, 0]) & (alpha_h <= dom[:, -1])):
+                return sum(np.interp(a, d, c) for a, d, c in zip(alpha_h, dom, cod))
+        at = _to_dev(alpha, self.cells.device)
+        return float(ops.cell_loglike(self._cr, at, swap=self._swap).sum().cpu())
+
+    def get_raw_lightcurve(self, tsmin=4):
+        """(ncell, 6) rows: MJD mid-time, half width (days), flux or upper
+        limit, lower error, upper error (-1 for limits), TS."""
+        aopt, ts, xlo, xhi = self.get_flux_all(conf=[0.159, 0.841])
+        rows = ops.lightcurve_rows(self.cells.starts, self.cells.stops, aopt, ts, xlo, xhi,
+                                   self._cr.S, tsmin)
+        out = np.empty([len(self.cells), 6])
+        out[:, 1:] = _np(rows)
+        tmid = 0.5 * (_np(self.cells.starts) + _np(self.cells.stops))
+        out[:, 0] = met2mjd(tmid)
+        return out
+
+
+class CellsLogLikelihoodOld(object):
+    """Flat photon layout for the direct trig sums (reference core.py:2388-2413)."""
+
+    def __init__(self, cells, device=None):
+        batch = _as_batch(cells, device=device)
+        self.cells = batch
+        self.nph = int((batch.hi - batch.lo).sum().cpu())
+        self.exp = batch.sexp
+        self.tmids = 0.5 * (batch.starts + batch.stops)
+        self._cr = batch.ranges()
+
+
+# ---------------------------------------------------------------------------
+# Data: the array tail of the reference's Data class (core.py:1792-1843, 1958-2206)
+# ---------------------------------------------------------------------------
+class Data(object):
+    """Photon list + exposure table.  File ingest (FITS, IRFs) is not part of
+    this package: construct from arrays."""
+
+    def __init__(self, ti, we, TSTART, TSTOP, LIVETIME, exposure, timeref='LOCAL', device=None,
+                 verbosity=1):
+        dev = device or default_device()
+        self.device = dev
+        self._verbosity = verbosity
+        self.timeref = timeref
+        self.ti = _to_dev(ti, dev)
+        self.we = _to_dev(we, dev)
+        self.TSTART = _to_dev(TSTART, dev)
+        self.TSTOP = _to_dev(TSTOP, dev)
+        self.LIVETIME = _to_dev(LIVETIME, dev)
+        self.exposure = _to_dev(exposure, dev)
+        # totals as the reference forms them (core.py:1583-1585)
+        if isinstance(we, torch.Tensor):
+            self.S = float(self.we.sum().cpu())
+        else:
+            self.S = float(np.sum(np.asarray(we, dtype=np.float64)))
+        self.B = self.we.numel() - self.S
+        if isinstance(exposure, torch.Tensor):
+            self.E = float(self.exposure.sum().cpu())
+        else:
+            self.E = float(np.sum(np.asarray(exposure, dtype=np.float64)))
+        self._exposure_table = None
+        self._t0 = float(self.TSTART[0].cpu())
+        self._t1 = float(self.TSTOP[-1].cpu())
+
+    def _vprint(self, s, level):
+        if self._verbosity >= level:
+            print(s)
+
+    def get_exposure(self, times, deadtime_too=False, cumulative=True):
+        """(exp, sexp, bexp, dead) at / between the given times."""
+        t = _to_dev(times, self.device)
+        if self._exposure_table is None:
+            # running sums of the exposure table: built once, reused by every query
+            self._exposure_table = ops.exposure_table(
+                self.TSTART, self.TSTOP, self.exposure, self.LIVETIME, self.S / self.E,
+                self.B / self.E)
+        return ops.exposure_at(self.TSTART, self.TSTOP, self.exposure, self.LIVETIME,
+                               self.S / self.E, self.B / self.E, self._exposure_table, t,
+                               cumulative=cumulative, deadtime_too=deadtime_too)
+
+    def get_cells(self, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True,
+                  time_series_only=False, use_barycenter=True, randomize=False, seed=None,
+                  src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
+                  minimum_fractional_exposure=0, quiet=False):
+        if use_barycenter:
+            raise NotImplementedError(
+                'use_barycenter=True needs the astropy ephemeris of the reference\'s bary '
+                'module, which this package does not carry; pass use_barycenter=False')
+        if randomize or (src_injector is not None) or (src_scaler is not None) \
+                or (bkg_scaler is not None):
+            raise NotImplementedError('randomize / scalers / injector are not built yet')
+        if tcell is None:
+            raise NotImplementedError('photon-based cells (tcell=None) are not built')
+        if tstart is None:
+            tstart = self._t0
+        tstart = float(infer_met(tstart))
+        if tstart < self._t0:
+            if not quiet:
+                print('Warning: Start time precedes start of exposure.')
+                print('Will clip to MET=%.2f.' % (self._t0))
+            tstart = self._t0
+        if tstop is None:
+            tstop = self._t1
+        tstop = float(infer_met(tstop))
+        if tstop > self._t1:
+            if not quiet:
+                print('Warning: Stop time follows end of exposure.')
+                print('Will clip to MET=%.2f.' % (self._t1))
+            tstop = self._t1
+
+        ncell = int((tstop - tstart) / tcell)
+        if ncell == 0:
+            tcell = tstop - tstart
+            ncell = 1
+        edges_h = tstart + np.arange(ncell + 1) * tcell
+        assert(edges_h[-1] <= tstop)
+        edges = torch.from_numpy(edges_h).to(self.device)
+        self._topo_edges = edges_h.copy()
+
+        exp, sexp, bexp, dead = self.get_exposure(edges, deadtime_too=True, cumulative=False)
+        starts, stops = edges[:-1].contiguous(), edges[1:].contiguous()
+
+        if minimum_fractional_exposure > 0:
+            frac = exp / exp[exp > 0].mean()
+            m = frac < minimum_fractional_exposure
+            exp[m] = 0
+            sexp[m] = 0
+            bexp[m] = 0
+
+        lo, hi, counts = ops.bin_photons(self.ti, float(edges_h[0]), stops)
+
+        if trim_zero_exposure:
+            keep = ops.select_cells(exp, 0.0)
+            starts, stops = ops.gather(starts, keep), ops.gather(stops, keep)
+            exp, sexp, bexp = ops.gather(exp, keep), ops.gather(sexp, keep), ops.gather(bexp, keep)
+            dead = ops.gather(dead, keep)
+            lo, hi, counts = ops.gather(lo, keep), ops.gather(hi, keep), ops.gather(counts, keep)
+
+        if time_series_only:
+            w1, w2 = ops.cell_moments(self.we, lo, hi)
+            return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
+                                  timesys='topocentric', minimum_exposure=0)
+        return CellBatch(self.we, self.ti, lo, hi, starts, stops, sexp, bexp)

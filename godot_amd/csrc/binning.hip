@@ -1,0 +1,402 @@
+// Exposure lookup and photon -> cell binning (gfx950).
+//
+// HBM-bound integer / fp64 streaming work: binary searches over sorted arrays
+// by one thread per query, tiled integer prefix scans (2048 elements per
+// 256-thread workgroup, three launches) for stream compaction, index gathers,
+// and one deliberately serial pass (the exposure running sums, see below).
+#include "common.hpp"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+struct Quad {
+    double a, b, c, d;
+};
+__device__ __forceinline__ Quad operator+(const Quad &x, const Quad &y)
+{
+    return Quad{x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d};
+}
+__device__ __forceinline__ Quad zero_of(Quad *) { return Quad{0, 0, 0, 0}; }
+__device__ __forceinline__ int64_t zero_of(int64_t *) { return 0; }
+
+__device__ __forceinline__ Quad shfl_up_v(const Quad &v, int o)
+{
+    return Quad{__shfl_up(v.a, o, WAVE), __shfl_up(v.b, o, WAVE), __shfl_up(v.c, o, WAVE),
+                __shfl_up(v.d, o, WAVE)};
+}
+__device__ __forceinline__ int64_t shfl_up_v(int64_t v, int o)
+{
+    return (int64_t)__shfl_up((long long)v, o, WAVE);
+}
+
+// Inclusive scan of one value per thread over the workgroup; returns the
+// inclusive prefix and writes the workgroup total to `total`.
+template <class V>
+__device__ V block_scan(V v, V &total)
+{
+    __shared__ V wave_tot[SCAN_THREADS / WAVE];
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        V u = shfl_up_v(v, o);
+        if (lane >= o) v = u + v;
+    }
+    if (lane == WAVE - 1) wave_tot[wave] = v;
+    __syncthreads();
+    V pre = zero_of((V *)nullptr);
+    V tot = zero_of((V *)nullptr);
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / WAVE; ++k) {
+        if (k < wave) pre = pre + wave_tot[k];
+        tot = tot + wave_tot[k];
+    }
+    __syncthreads();
+    total = tot;
+    return pre + v;
+}
+
+// pass 1: per-tile totals
+template <class V, class Load>
+__global__ __launch_bounds__(SCAN_THREADS) void tile_reduce_kernel(Load ld, int64_t n, V *partials)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    V s = zero_of((V *)nullptr);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s = s + ld(base + k);
+    V tot;
+    block_scan(s, tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// pass 2: exclusive scan of the tile totals by one workgroup
+template <class V>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_partials_kernel(V *partials, int64_t ntiles, V *grand)
+{
+    V carry = zero_of((V *)nullptr);
+    for (int64_t base = 0; base < ntiles; base += SCAN_THREADS) {
+        int64_t i = base + threadIdx.x;
+        V v = (i < ntiles) ? partials[i] : zero_of((V *)nullptr);
+        V tot;
+        V incl = block_scan(v, tot);
+        // exclusive prefix = inclusive prefix of the previous thread
+        __shared__ V incl_s[SCAN_THREADS];
+        incl_s[threadIdx.x] = incl;
+        __syncthreads();
+        V excl = (threadIdx.x == 0) ? zero_of((V *)nullptr) : incl_s[threadIdx.x - 1];
+        if (i < ntiles) partials[i] = carry + excl;
+        carry = carry + tot;
+        __syncthreads();
+    }
+    if (grand && threadIdx.x == 0) *grand = carry;
+}
+
+// pass 3: scan inside each tile, add the tile prefix, hand each inclusive
+// value to `st`
+template <class V, class Load, class Store>
+__global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(Load ld, int64_t n, const V *partials,
+                                                                 Store st)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    V x[SCAN_ITEMS];
+    V s = zero_of((V *)nullptr);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        x[k] = (base + k < n) ? ld(base + k) : zero_of((V *)nullptr);
+        s = s + x[k];
+        x[k] = s;   // thread-local inclusive
+    }
+    V tot;
+    V incl = block_scan(s, tot);
+    __shared__ V incl_s[SCAN_THREADS];
+    incl_s[threadIdx.x] = incl;
+    __syncthreads();
+    V pre = partials[blockIdx.x];
+    if (threadIdx.x > 0) pre = pre + incl_s[threadIdx.x - 1];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) st(base + k, pre + x[k]);
+}
+
+// first index i in [0, n) with a[i] >= v (numpy searchsorted side='left')
+__device__ __forceinline__ int64_t lower_bound(const double *a, int64_t n, double v)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// first index with a[i] > v (side='right')
+__device__ __forceinline__ int64_t upper_bound(const double *a, int64_t n, double v)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct ExposureLoad {
+    const double *tstart, *tstop, *exposure, *livetime;
+    double s_over_e, b_over_e;
+    __device__ Quad operator()(int64_t i) const
+    {
+        double e = exposure[i];
+        // (S/E)*exposure, (B/E)*exposure: core.py:1821-1824
+        // dead time (TSTOP-TSTART)-LIVETIME: core.py:1831
+        return Quad{e, __dmul_rn(s_over_e, e), __dmul_rn(b_over_e, e),
+                    __dsub_rn(__dsub_rn(tstop[i], tstart[i]), livetime[i])};
+    }
+};
+struct QuadStore {
+    Quad *out;
+    __device__ void operator()(int64_t i, const Quad &v) const { out[i] = v; }
+};
+
+// numpy.cumsum adds left to right, and which cells end up with an exposure of
+// exactly zero (and are trimmed, core.py:2110-2122) depends on that rounding
+// order.  To reproduce it bit for bit the running sums are formed serially:
+// the workgroup stages a tile of the four series in LDS, four lanes (one per
+// series) walk the tile carrying their running sum, and the workgroup stores
+// the tile.  One workgroup; about 10 cycles per table row.  The table depends
+// only on the exposure table, so callers keep it across queries.
+constexpr int SEQ_TILE = 2048;
+
+__global__ __launch_bounds__(256) void exposure_cumsum_kernel(ExposureLoad ld, int64_t n, Quad *cum)
+{
+    __shared__ double s_x[4][SEQ_TILE + 1];
+    double carry = 0.0;   // lanes 0..3 of wave 0: running sum of series `lane`
+    for (int64_t base = 0; base < n; base += SEQ_TILE) {
+        const int m = (int)((n - base) < SEQ_TILE ? (n - base) : SEQ_TILE);
+        for (int k = threadIdx.x; k < m; k += blockDim.x) {
+            Quad q = ld(base + k);
+            s_x[0][k] = q.a;
+            s_x[1][k] = q.b;
+            s_x[2][k] = q.c;
+            s_x[3][k] = q.d;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double *row = s_x[threadIdx.x];
+            double s = carry;
+#pragma unroll 8
+            for (int k = 0; k < m; ++k) {
+                s = __dadd_rn(s, row[k]);
+                row[k] = s;
+            }
+            carry = s;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < m; k += blockDim.x)
+            cum[base + k] = Quad{s_x[0][k], s_x[1][k], s_x[2][k], s_x[3][k]};
+        __syncthreads();
+    }
+}
+
+// cumulative exposures at the query times: core.py:1806-1832
+__global__ void exposure_query_kernel(ExposureLoad ld, const Quad *cum, int64_t n_ft2, const double *times,
+                                      int64_t n_t, Quad *at)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_t) return;
+    double t = times[k];
+    int64_t idx = lower_bound(ld.tstop, n_ft2, t);
+    if (idx >= n_ft2) idx = n_ft2 - 1;   // the reference would index out of range here
+    double t0 = ld.tstart[idx], t1 = ld.tstop[idx];
+    double frac = __ddiv_rn(__dsub_rn(t, t0), __dsub_rn(t1, t0));
+    frac = frac < 0 ? 0.0 : (frac > 1 ? 1.0 : frac);   // np.clip keeps NaN
+    frac = 1 - frac;
+    Quad x = ld(idx), c = cum[idx];
+    at[k] = Quad{__dsub_rn(c.a, __dmul_rn(x.a, frac)), __dsub_rn(c.b, __dmul_rn(x.b, frac)),
+                 __dsub_rn(c.c, __dmul_rn(x.c, frac)), __dsub_rn(c.d, __dmul_rn(x.d, frac))};
+}
+
+__global__ void exposure_out_kernel(const Quad *at, int64_t n_out, int cumulative, double *o_exp,
+                                    double *o_sexp, double *o_bexp, double *o_dead)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    Quad v = at[k];
+    if (!cumulative) {
+        Quad u = at[k + 1];
+        v = Quad{u.a - v.a, u.b - v.b, u.c - v.c, u.d - v.d};
+    }
+    o_exp[k] = v.a;
+    o_sexp[k] = v.b;
+    o_bexp[k] = v.c;
+    if (o_dead) o_dead[k] = v.d;
+}
+
+// photon range of every cell (see godot_bin_photons in the header)
+__global__ void bin_photons_kernel(const double *ti, int64_t nph, double start0, const double *stops,
+                                   int64_t ncell, int64_t *lo, int64_t *hi, int64_t *counts)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    int64_t l = (c == 0) ? lower_bound(ti, nph, start0) : upper_bound(ti, nph, stops[c - 1]);
+    int64_t h = (c == ncell - 1) ? lower_bound(ti, nph, stops[c]) : upper_bound(ti, nph, stops[c]);
+    if (h < l) h = l;   // start0 beyond the first stop: empty first cell
+    lo[c] = l;
+    hi[c] = h;
+    if (counts) counts[c] = h - l;
+}
+
+struct MaskLoad {
+    const double *exp;
+    double thr;
+    __device__ int64_t operator()(int64_t i) const { return exp[i] > thr ? 1 : 0; }
+};
+struct SelectStore {
+    const double *exp;
+    double thr;
+    int64_t *keep;
+    __device__ void operator()(int64_t i, int64_t incl) const
+    {
+        if (exp[i] > thr) keep[incl - 1] = i;
+    }
+};
+
+template <class T>
+__global__ void gather_kernel(const T *src, const int64_t *idx, int64_t n, T *dst)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[idx[k]];
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}   // namespace
+
+extern "C" size_t godot_exposure_table_bytes(int64_t n_ft2)
+{
+    return n_ft2 < 0 ? 0 : align256(sizeof(Quad) * (size_t)n_ft2);
+}
+
+extern "C" int godot_exposure_table(const double *tstart, const double *tstop, const double *exposure,
+                                    const double *livetime, int64_t n_ft2, double s_over_e,
+                                    double b_over_e, void *table, size_t table_bytes,
+                                    godot_stream_t stream)
+{
+    GODOT_REQUIRE(n_ft2 > 0, GODOT_E_INVALID, "godot_exposure_table: n_ft2 must be positive");
+    GODOT_REQUIRE(tstart && tstop && exposure && livetime, GODOT_E_INVALID,
+                  "godot_exposure_table: null table pointer");
+    GODOT_REQUIRE(table && table_bytes >= godot_exposure_table_bytes(n_ft2), GODOT_E_WORKSPACE,
+                  "godot_exposure_table: table smaller than godot_exposure_table_bytes(n_ft2)");
+    ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
+    hipLaunchKernelGGL(exposure_cumsum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ld, n_ft2,
+                       (Quad *)table);
+    GODOT_LAUNCH_CHECK("godot_exposure_table");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_exposure_workspace_bytes(int64_t n_t)
+{
+    return n_t < 0 ? 0 : align256(sizeof(Quad) * (size_t)n_t);
+}
+
+extern "C" int godot_exposure_at(const double *tstart, const double *tstop, const double *exposure,
+                                 const double *livetime, int64_t n_ft2, double s_over_e, double b_over_e,
+                                 const void *table, const double *times, int64_t n_t, int cumulative,
+                                 double *out_exp, double *out_sexp, double *out_bexp, double *out_dead,
+                                 void *workspace, size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n_ft2 > 0 && n_t >= 0, GODOT_E_INVALID, "godot_exposure_at: bad sizes");
+    GODOT_REQUIRE(tstart && tstop && exposure && livetime && table, GODOT_E_INVALID,
+                  "godot_exposure_at: null table pointer");
+    if (n_t == 0) return GODOT_OK;
+    GODOT_REQUIRE(times && out_exp && out_sexp && out_bexp, GODOT_E_INVALID,
+                  "godot_exposure_at: null query/output pointer");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_exposure_workspace_bytes(n_t), GODOT_E_WORKSPACE,
+                  "godot_exposure_at: workspace smaller than godot_exposure_workspace_bytes(n_t)");
+    hipStream_t st = (hipStream_t)stream;
+    Quad *at = (Quad *)workspace;
+    ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
+    hipLaunchKernelGGL(exposure_query_kernel, dim3((unsigned)ceil_div(n_t, 256)), dim3(256), 0, st, ld,
+                       (const Quad *)table, n_ft2, times, n_t, at);
+    int64_t n_out = cumulative ? n_t : n_t - 1;
+    if (n_out > 0)
+        hipLaunchKernelGGL(exposure_out_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st,
+                           (const Quad *)at, n_out, cumulative, out_exp, out_sexp, out_bexp, out_dead);
+    GODOT_LAUNCH_CHECK("godot_exposure_at");
+    return GODOT_OK;
+}
+
+extern "C" int godot_bin_photons(const double *ti, int64_t nph, double start0, const double *stops,
+                                 int64_t ncell, int64_t *lo, int64_t *hi, int64_t *counts,
+                                 godot_stream_t stream)
+{
+    GODOT_REQUIRE(nph >= 0 && ncell >= 0, GODOT_E_INVALID, "godot_bin_photons: negative size");
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE((ti || nph == 0) && stops && lo && hi, GODOT_E_INVALID,
+                  "godot_bin_photons: null argument");
+    hipLaunchKernelGGL(bin_photons_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ti, nph, start0, stops, ncell, lo, hi, counts);
+    GODOT_LAUNCH_CHECK("godot_bin_photons");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_select_workspace_bytes(int64_t ncell)
+{
+    if (ncell < 0) return 0;
+    return align256(sizeof(int64_t) * ((size_t)ceil_div(ncell, SCAN_TILE) + 1));
+}
+
+extern "C" int godot_select_cells(const double *exp, int64_t ncell, double threshold, int64_t *keep_idx,
+                                  int64_t *n_keep, void *workspace, size_t workspace_bytes,
+                                  godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_select_cells: negative ncell");
+    GODOT_REQUIRE(n_keep, GODOT_E_INVALID, "godot_select_cells: null n_keep");
+    hipStream_t st = (hipStream_t)stream;
+    if (ncell == 0) {
+        (void)hipMemsetAsync(n_keep, 0, sizeof(int64_t), st);
+        return GODOT_OK;
+    }
+    GODOT_REQUIRE(exp && keep_idx, GODOT_E_INVALID, "godot_select_cells: null argument");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_select_workspace_bytes(ncell), GODOT_E_WORKSPACE,
+                  "godot_select_cells: workspace too small");
+    int64_t ntiles = ceil_div(ncell, SCAN_TILE);
+    int64_t *part = (int64_t *)workspace;
+    MaskLoad ld{exp, threshold};
+    hipLaunchKernelGGL((tile_reduce_kernel<int64_t, MaskLoad>), dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0,
+                       st, ld, ncell, part);
+    hipLaunchKernelGGL((scan_partials_kernel<int64_t>), dim3(1), dim3(SCAN_THREADS), 0, st, part, ntiles,
+                       n_keep);
+    hipLaunchKernelGGL((tile_scan_kernel<int64_t, MaskLoad, SelectStore>), dim3((unsigned)ntiles),
+                       dim3(SCAN_THREADS), 0, st, ld, ncell, (const int64_t *)part,
+                       SelectStore{exp, threshold, keep_idx});
+    GODOT_LAUNCH_CHECK("godot_select_cells");
+    return GODOT_OK;
+}
+
+extern "C" int godot_gather_f64(const double *src, const int64_t *idx, int64_t n, double *dst,
+                                godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_gather_f64: negative n");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(src && idx && dst, GODOT_E_INVALID, "godot_gather_f64: null argument");
+    hipLaunchKernelGGL(gather_kernel<double>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, idx, n, dst);
+    GODOT_LAUNCH_CHECK("godot_gather_f64");
+    return GODOT_OK;
+}
+
+extern "C" int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n, int64_t *dst,
+                                godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_gather_i64: negative n");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(src && idx && dst, GODOT_E_INVALID, "godot_gather_i64: null argument");
+    hipLaunchKernelGGL(gather_kernel<int64_t>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, idx, n, dst);
+    GODOT_LAUNCH_CHECK("godot_gather_i64");
+    return GODOT_OK;
+}

@@ -534,8 +534,10 @@ __device__ Support support_search(const CellData<T, R> &cd, double S, double aop
 // numpy.linspace(amin, amax, npt)[i]
 __device__ __forceinline__ double grid_point(double amin, double amax, double step, int i, int npt)
 {
+#pragma clang fp contract(off)   // numpy rounds the product before the sum
     if (i == npt - 1 && npt > 1) return amax;
-    return __dadd_rn(__dmul_rn((double)i, step), amin);
+    double prod = (double)i * step;
+    return prod + amin;
 }
 
 __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const double *aopt_in, double dlogl,

@@ -163,3 +163,83 @@ def cell_moments(we, lo, hi):
         _lib.call('godot_cell_moments', _p(we), we.numel(), _p(lo), _p(hi), n, _p(w1), _p(w2),
                   _stream(dev))
     return w1, w2
+
+
+# ---------------------------------------------------------------------------
+# binning
+# ---------------------------------------------------------------------------
+def _workspace(nbytes, dev):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def exposure_table(tstart, tstop, exposure, livetime, s_over_e, b_over_e):
+    """Left-to-right running sums of the four exposure series (device blob)."""
+    for t, nm in ((tstart, 'TSTART'), (tstop, 'TSTOP'), (exposure, 'exposure'),
+                  (livetime, 'LIVETIME')):
+        _dev_check(t, F64, nm)
+    n_ft2, dev = tstart.numel(), tstart.device
+    if not (tstop.numel() == exposure.numel() == livetime.numel() == n_ft2):
+        raise ValueError('TSTART, TSTOP, exposure, LIVETIME must have equal lengths')
+    table = _workspace(_lib.lib.godot_exposure_table_bytes(n_ft2), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_exposure_table', _p(tstart), _p(tstop), _p(exposure), _p(livetime), n_ft2,
+                  float(s_over_e), float(b_over_e), _p(table), table.numel(), _stream(dev))
+    return table
+
+
+def exposure_at(tstart, tstop, exposure, livetime, s_over_e, b_over_e, table, times,
+                cumulative=True, deadtime_too=True):
+    _dev_check(times, F64, 'times')
+    n_ft2, n_t, dev = tstart.numel(), times.numel(), times.device
+    n_out = n_t if cumulative else max(n_t - 1, 0)
+    outs = [torch.empty(n_out, dtype=F64, device=dev) for _ in range(4 if deadtime_too else 3)]
+    ws = _workspace(_lib.lib.godot_exposure_workspace_bytes(n_t), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_exposure_at', _p(tstart), _p(tstop), _p(exposure), _p(livetime), n_ft2,
+                  float(s_over_e), float(b_over_e), _p(table), _p(times), n_t,
+                  int(bool(cumulative)), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                  _p(outs[3]) if deadtime_too else 0, _p(ws), ws.numel(), _stream(dev))
+    return outs[0], outs[1], outs[2], (outs[3] if deadtime_too else None)
+
+
+def bin_photons(ti, start0, stops):
+    _dev_check(ti, F64, 'ti')
+    _dev_check(stops, F64, 'stops')
+    n, dev = stops.numel(), ti.device
+    lo = torch.empty(n, dtype=I64, device=dev)
+    hi = torch.empty(n, dtype=I64, device=dev)
+    counts = torch.empty(n, dtype=I64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_bin_photons', _p(ti), ti.numel(), float(start0), _p(stops), n, _p(lo),
+                  _p(hi), _p(counts), _stream(dev))
+    return lo, hi, counts
+
+
+def select_cells(exp, threshold=0.0):
+    """Ascending indices of the cells with exp > threshold (synchronises once
+    to learn how many there are)."""
+    _dev_check(exp, F64, 'exp')
+    n, dev = exp.numel(), exp.device
+    keep = torch.empty(n, dtype=I64, device=dev)
+    nk = torch.zeros(1, dtype=I64, device=dev)
+    ws = _workspace(_lib.lib.godot_select_workspace_bytes(n), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_select_cells', _p(exp), n, float(threshold), _p(keep), _p(nk), _p(ws),
+                  ws.numel(), _stream(dev))
+    return keep[:int(nk.item())]
+
+
+def gather(src, idx):
+    _dev_check(idx, I64, 'idx')
+    n, dev = idx.numel(), src.device
+    dst = torch.empty(n, dtype=src.dtype, device=dev)
+    if src.dtype == F64:
+        name = 'godot_gather_f64'
+    elif src.dtype == I64:
+        name = 'godot_gather_i64'
+    else:
+        raise TypeError('gather supports float64 and int64')
+    _dev_check(src, src.dtype, 'src')
+    with torch.cuda.device(dev):
+        _lib.call(name, _p(src), _p(idx), n, _p(dst), _stream(dev))
+    return dst

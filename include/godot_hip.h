@@ -126,16 +126,29 @@ int godot_cell_beta_max(const double *we, int64_t nph,
 
 /* ---- binning: Data.get_exposure / Data.get_cells, core.py:1792-1843, 2063-2206 */
 
-/* Bytes of workspace godot_exposure_at needs for a table of n_ft2 rows.       */
-size_t godot_exposure_workspace_bytes(int64_t n_ft2);
+/* Running sums of the exposure table (np.cumsum at core.py:1826-1832) for the
+ * four series exposure, (S/E) exposure, (B/E) exposure and dead time
+ * (TSTOP-TSTART)-LIVETIME, added left to right exactly as numpy does so that
+ * differences of the sums (and therefore the zero-exposure trimming mask) are
+ * bit-identical to the reference's.  `table` (device, godot_exposure_table_bytes
+ * bytes) depends only on the exposure table and the two scale factors: build it
+ * once, reuse it for every godot_exposure_at call.                            */
+size_t godot_exposure_table_bytes(int64_t n_ft2);
+int godot_exposure_table(const double *tstart, const double *tstop,
+                         const double *exposure, const double *livetime,
+                         int64_t n_ft2, double s_over_e, double b_over_e,
+                         void *table, size_t table_bytes, godot_stream_t stream);
 
 /* Exposure, source-scaled exposure, background-scaled exposure and dead time
  * at the query times (cumulative != 0) or between consecutive query times
  * (cumulative == 0: outputs have n_t - 1 entries).  Replaces
- * Data.get_exposure (core.py:1806-1841).  out_dead may be NULL.               */
+ * Data.get_exposure (core.py:1806-1841).  out_dead may be NULL.
+ * workspace: godot_exposure_workspace_bytes(n_t).                             */
+size_t godot_exposure_workspace_bytes(int64_t n_t);
 int godot_exposure_at(const double *tstart, const double *tstop,
                       const double *exposure, const double *livetime,
                       int64_t n_ft2, double s_over_e, double b_over_e,
+                      const void *table,
                       const double *times, int64_t n_t, int cumulative,
                       double *out_exp, double *out_sexp, double *out_bexp,
                       double *out_dead, void *workspace, size_t workspace_bytes,

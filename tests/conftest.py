@@ -29,3 +29,15 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+def assert_same(got, want, what=''):
+    """Bit-for-bit equality (NaN == NaN) with a short failure message."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, '%s: shape %s vs %s' % (what, got.shape, want.shape)
+    bad = ~((got == want) | ((got != got) & (want != want)))
+    if bad.any():
+        i = np.argwhere(bad)[:4]
+        raise AssertionError('%s: %d of %d differ, first at %s: got %r want %r' % (
+            what, bad.sum(), bad.size, i.tolist(), got[bad][:4].tolist(), want[bad][:4].tolist()))

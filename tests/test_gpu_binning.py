@@ -1,0 +1,113 @@
+"""GPU parity of exposure lookup and photon->cell binning (through the
+reference-shaped Data.get_cells API) against the reference's golden vectors
+and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import godot_oracle as orc
+from conftest import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(g):
+    from godot_amd import core
+    return core.Data(g['in_ti'], g['in_we'], g['in_TSTART'], g['in_TSTOP'], g['in_LIVETIME'],
+                     g['in_exposure'])
+
+
+def _n(t):
+    return t.cpu().numpy()
+
+
+def test_exposure_matches_reference(golden):
+    g = golden('exposure.npz')
+    d = _data(g)
+    assert d.S == float(g['in_S']) and d.E == float(g['in_E'])
+    c = d.get_exposure(g['times'], deadtime_too=True, cumulative=True)
+    # the running sums are formed in numpy's order: bit-identical, not just close
+    for k in range(4):
+        assert_same(_n(c[k]), g['cumulative'][k], "g['cumulative'][k]")
+    dd = d.get_exposure(g['times'], deadtime_too=True, cumulative=False)
+    for k in range(4):
+        assert_same(_n(dd[k]), g['differential'][k], "g['differential'][k]")
+
+
+@pytest.mark.parametrize('name', ['cells_dense.npz', 'cells_sparse.npz'])
+def test_get_cells_matches_reference(golden, name):
+    g = golden(name)
+    d = _data(g)
+    cells = d.get_cells(tcell=float(g['tcell']), use_barycenter=False)
+    assert len(cells) == len(g['counts'])
+    assert_same(_n(cells.starts), g['starts'], "g['starts']")
+    assert_same(_n(cells.stops), g['stops'], "g['stops']")
+    lo, hi = _n(cells.lo), _n(cells.hi)
+    assert np.array_equal(hi - lo, g['counts'])            # bit-exact integer part
+    we = np.concatenate([g['in_we'][a:b] for a, b in zip(lo, hi)])
+    ti = np.concatenate([g['in_ti'][a:b] for a, b in zip(lo, hi)])
+    assert_same(we, g['we']) and np.array_equal(ti, g['ti'], "g['ti']")
+    assert_same(_n(cells.sexp), g['exp'], "g['exp']")
+    assert_same(_n(cells.sexp) / _n(cells.bexp), g['SonB'], "g['SonB']")
+    # a Cell materialised from the batch looks like the reference's
+    c = cells[3]
+    assert c.tstart == g['starts'][3] and len(c.we) == g['counts'][3]
+    c.sanity_check()
+
+
+def test_time_series_matches_reference(golden):
+    g = golden('timeseries_fft.npz')
+    d = _data(g)
+    ts = d.get_cells(tcell=float(g['tcell']), time_series_only=True, trim_zero_exposure=False,
+                     use_barycenter=False)
+    assert_same(_n(ts.starts), g['starts'], "g['starts']")
+    assert np.array_equal(_n(ts.counts), g['counts'])      # bit-exact
+    for k, gk in (('exp', 'exp'), ('sexp', 'sexp'), ('bexp', 'bexp'), ('deadtime', 'deadtime')):
+        assert_same(_n(getattr(ts, k)), g[gk], 'g[gk]')
+    assert np.allclose(_n(ts.weights), g['weights'], rtol=1e-12, atol=1e-13)
+    assert np.allclose(_n(ts.weights2), g['weights2'], rtol=1e-12, atol=1e-13)
+    assert ts.tsamp() == g['stops'][0] - g['starts'][0]
+    assert ts.ps_nbin() == len(g['starts']) // 4 + 1
+
+
+def test_binning_edge_semantics():
+    """Photon on an edge goes to the earlier cell; the first edge is closed,
+    the last open (numpy searchsorted side='left' on stops)."""
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    stops = np.array([10., 20., 30.])
+    ti = np.array([-1., 0., 0., 5., 10., 10., 10.000001, 20., 29.999, 30., 31.])
+    start0 = 0.
+    lo, hi, cnt = ops.bin_photons(torch.from_numpy(ti).to(dev), start0, torch.from_numpy(stops).to(dev))
+    sl = slice(*np.searchsorted(ti, [start0, stops[-1]]))
+    ref = np.bincount(np.searchsorted(stops, ti[sl]), minlength=3)
+    assert np.array_equal(_n(cnt), ref)
+    assert _n(lo)[0] == 1 and _n(hi)[-1] == 9
+    # empty photon list, and a single cell
+    lo, hi, cnt = ops.bin_photons(torch.empty(0, dtype=torch.float64, device=dev), 0.,
+                                  torch.from_numpy(stops).to(dev))
+    assert _n(cnt).sum() == 0
+    lo, hi, cnt = ops.bin_photons(torch.from_numpy(ti).to(dev), 0., torch.tensor([30.], dtype=torch.float64, device=dev))
+    assert _n(cnt)[0] == 8
+
+
+def test_large_binning_matches_oracle_and_conserves_photons():
+    """1e6 photons into 10-minute cells: integer layout bit-exact vs the oracle."""
+    from godot_amd import core, synth
+    s = synth.synth(1000000, years=1.0, seed=11)
+    d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'])
+    cells = d.get_cells(tcell=600., use_barycenter=False)
+    b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'],
+                      s['S'], s['B'], s['E'], tcell=600.)
+    lo, hi = _n(cells.lo), _n(cells.hi)
+    assert_same(hi - lo, b['counts'], "b['counts']")
+    assert_same(_n(cells.starts), b['starts'], "b['starts']")
+    # kept photons are exactly the oracle's, in order
+    idx = np.concatenate([np.arange(a, c) for a, c in zip(lo[:2000], hi[:2000])])
+    nn = len(idx)
+    assert np.array_equal(s['we'][idx], b['weights'][:nn])
+    assert (hi - lo).sum() == len(b['weights'])
+    assert_same(_n(cells.sexp), b['sexp'], "b['sexp']")
+    assert_same(_n(cells.bexp), b['bexp'], "b['bexp']")
+    ts = d.get_cells(tcell=600., use_barycenter=False, time_series_only=True, trim_zero_exposure=False)
+    assert int(_n(ts.counts).sum()) == np.searchsorted(s['ti'], _n(ts.stops)[-1]) - np.searchsorted(s['ti'], _n(ts.starts)[0])
