@@ -19,7 +19,8 @@ from . import ops
 
 __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries',
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
-           'met2mjd', 'mjd2met', 'infer_met']
+           'met2mjd', 'mjd2met', 'infer_met', 'power_spectrum_fft', 'power_spectrum_simple',
+           'power_spectrum_dft', 'fit_harmonics', 'z2m', 'h_test']
 
 MJDREF = 51910 + 7.428703703703703e-4
 F64 = torch.float64
@@ -565,3 +566,125 @@ class Data(object):
             return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
                                   timesys='topocentric', minimum_exposure=0)
         return CellBatch(self.we, self.ti, lo, hi, starts, stops, sexp, bexp)
+
+
+# ---------------------------------------------------------------------------
+# Power spectra (reference core.py:2598-2782) and trig sums (2426-2596)
+# ---------------------------------------------------------------------------
+def _ts_dev(ts, name, dev):
+    return _to_dev(getattr(ts, name), dev)
+
+
+def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False, get_amps=False,
+                       exposure_correction=None, no_zero_pad=False, maxN=None, device=None):
+    """FFT evaluation of the first-order likelihood power spectra.  Returns
+    (frequencies [Hz], P_0, P_1, P_b) as numpy arrays, or the amplitude tuple
+    of get_amps=True, exactly as the reference orders them."""
+    cells = timeseries
+    dev = device or (cells.weights.device if isinstance(cells.weights, torch.Tensor)
+                     else default_device())
+    W = _ts_dev(cells, 'weights', dev)
+    WW = _ts_dev(cells, 'weights2', dev)
+    S = _ts_dev(cells, 'sexp', dev)
+    counts = _to_dev(cells.counts, dev, F64) if not (isinstance(cells.counts, torch.Tensor)
+                                                    and cells.counts.dtype == F64) \
+        else cells.counts.to(dev)
+    if exposure_correction is not None:
+        S = S * _to_dev(exposure_correction, dev)
+    if tweak_exp:
+        S = S * W.sum() / S.sum()
+    Wb = counts - W
+    WbWb = counts - 2 * W + WW
+    B = _ts_dev(cells, 'bexp', dev)
+    if tweak_exp:
+        B = B * Wb.sum() / B.sum()
+    if maxN is not None:
+        W, WW, Wb, WbWb, S, B = [x[:maxN].contiguous() for x in (W, WW, Wb, WbWb, S, B)]
+    if exp_only:
+        W = 2 * S - S.mean()
+
+    if dfgoal is None:
+        dfgoal = 0.2 / cells.tspan()
+    nfft = 1. / (cells.tsamp() * dfgoal)
+    l = 2 ** (int(np.log2(nfft)) + 1)
+    if no_zero_pad:
+        l = W.numel()
+    if l & (l - 1):
+        raise NotImplementedError('transform length %d is not a power of two' % l)
+    if l < W.numel():
+        raise NotImplementedError('dfgoal gives a transform shorter than the series')
+    freqs = np.fft.rfftfreq(l)[:l // 4 + 1] / cells.tsamp()
+    p0, p1, pb, amps = ops.power_spectrum_fft(W.contiguous(), WW.contiguous(), S.contiguous(),
+                                              Wb.contiguous(), WbWb.contiguous(), B.contiguous(),
+                                              l, want_amps=get_amps)
+    if get_amps:
+        a = _np(amps)
+        return (freqs,) + tuple(a[i] for i in range(8))
+    if exp_only:
+        return freqs, _np(p0)
+    return freqs, _np(p0), _np(p1), _np(pb)
+
+
+def power_spectrum_simple(timeseries, get_amps=False, device=None):
+    ts = timeseries
+    dev = device or (ts.weights.device if isinstance(ts.weights, torch.Tensor) else default_device())
+    W, WW, S = _ts_dev(ts, 'weights', dev), _ts_dev(ts, 'weights2', dev), _ts_dev(ts, 'sexp', dev)
+    l = W.numel()
+    if l & (l - 1):
+        raise NotImplementedError('series length %d is not a power of two' % l)
+    dl, mom = ops.power_spectrum_simple(W, WW, S, want_moments=get_amps)
+    freqs = np.fft.rfftfreq(l)[:(l // 4 + 1)] * (1. / ts.tsamp())
+    if get_amps:
+        m = _np(mom)
+        return freqs, _np(dl), (m[0], m[1], m[2], m[3])
+    return freqs, _np(dl)
+
+
+def power_spectrum_dft(cll, freqs, unweighted=False):
+    """First-order likelihood spectrum at arbitrary frequencies on possibly
+    uneven cells (cll: a CellsLogLikelihoodOld)."""
+    cr = cll._cr
+    dev = cr.device
+    w1, w2 = ops.cell_moments(cr.we, cr.lo, cr.hi)
+    scale = 1.0
+    if unweighted:
+        # unit weights: both moments are the counts; exposure rescaled by nph / sum(w)
+        scale = float(cll.nph) / float(w1.sum().cpu())
+        w1 = (cr.hi - cr.lo).to(F64)
+        w2 = w1.clone()
+    out = ops.trigsum_cells(w1, w2, cll.exp.contiguous(), cll.tmids.contiguous(),
+                            _to_dev(freqs, dev), exp_scale=scale)
+    return _np(out)
+
+
+def fit_harmonics(cll, freq):
+    """Best-fitting cos/sin amplitudes and TS at one frequency (or an array of
+    frequencies: then an (n, 3) array)."""
+    cr = cll._cr
+    dev = cr.device
+    w1, w2 = ops.cell_moments(cr.we, cr.lo, cr.hi)
+    f = np.atleast_1d(np.asarray(freq, dtype=np.float64))
+    tmean = float(np.mean(_np(cll.tmids)))
+    out = _np(ops.fit_harmonics(w1, w2, cll.exp.contiguous(), cll.tmids.contiguous(), tmean,
+                                _to_dev(f, dev)))
+    if np.ndim(freq) == 0:
+        return out[0, 0], out[0, 1], out[0, 2]
+    return out
+
+
+def z2m(times, weights, f0, df, nf, m=2, j0=0, device=None):
+    """Weighted Z^2_m on the grid f0 + (j0 + j) df (device tensor of nf values).
+    Not part of the reference: see godot_z2m in include/godot_hip.h."""
+    dev = device or (times.device if isinstance(times, torch.Tensor) and times.is_cuda
+                     else default_device())
+    z, _ = ops.z2m(_to_dev(times, dev), _to_dev(weights, dev), f0, df, nf, m=m, j0=j0)
+    return z
+
+
+def h_test(times, weights, f0, df, nf, mmax=20, j0=0, device=None):
+    """Weighted H statistic max_{m<=mmax}(Z^2_m - 4m + 4) on the same grid."""
+    dev = device or (times.device if isinstance(times, torch.Tensor) and times.is_cuda
+                     else default_device())
+    _, h = ops.z2m(_to_dev(times, dev), _to_dev(weights, dev), f0, df, nf, m=mmax, j0=j0,
+                   want_z2=False, want_h=True)
+    return h

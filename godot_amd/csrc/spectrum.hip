@@ -1,0 +1,408 @@
+// Real FFTs of the binned light curve and the likelihood power-spectrum
+// epilogue (gfx950).
+//
+// A real series of (zero-padded) length l is transformed as a complex series
+// of length N = l/2 (even samples -> real parts, odd samples -> imaginary
+// parts) followed by the split into the real transform's bins.  The complex
+// transform is a Stockham autosort FFT: radix-16 passes ping-ponging between
+// two HBM buffers (one thread = one 16-point butterfly held in registers,
+// reads coalesced, writes in runs of >= 256 bytes), plus one radix-2/4/8 pass
+// when log2 N is not a multiple of 4.  Twiddles are computed in registers from
+// an exactly reduced angle, so no table is read.  HBM-bound: each pass moves
+// 32 bytes per complex point.
+#include "common.hpp"
+
+namespace {
+
+struct cplx {
+    double x, y;
+};
+__device__ __forceinline__ cplx operator+(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cplx operator-(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+    return cplx{fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)};
+}
+
+constexpr double TWO_PI_HI = 6.283185307179586232e+00;
+constexpr double TWO_PI_LO = 2.449293598294706414e-16;
+
+// exp(2 pi i x) for |x| <= 0.5
+__device__ __forceinline__ cplx expi_cycles(double x)
+{
+    double q = rint(4.0 * x);
+    double r = fma(q, -0.25, x);
+    double th = fma(r, TWO_PI_HI, r * TWO_PI_LO);
+    double z = th * th;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double sn = fma(th * z, ps, th);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    int qi = (int)q & 3;
+    double s1 = (qi & 1) ? cs : sn;
+    double c1 = (qi & 1) ? sn : cs;
+    return cplx{((qi + 1) & 2) ? -c1 : c1, (qi & 2) ? -s1 : s1};
+}
+
+// exp(-2 pi i k / 16), k = 0..7
+__device__ __forceinline__ cplx w16(int k)
+{
+    constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, H = 0.70710678118654752440;
+    switch (k) {
+    case 0: return cplx{1.0, 0.0};
+    case 1: return cplx{C1, -S1};
+    case 2: return cplx{H, -H};
+    case 3: return cplx{S1, -C1};
+    case 4: return cplx{0.0, -1.0};
+    case 5: return cplx{-S1, -C1};
+    case 6: return cplx{-H, -H};
+    default: return cplx{-C1, -S1};
+    }
+}
+
+// In-register forward DFT of R points (R = 2, 4, 8, 16), natural order in and
+// out: recursive decimation in time, fully unrolled.
+template <int R>
+__device__ __forceinline__ void dft(cplx (&v)[R])
+{
+    if constexpr (R == 2) {
+        cplx a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    } else {
+        cplx e[R / 2], o[R / 2];
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            e[k] = v[2 * k];
+            o[k] = v[2 * k + 1];
+        }
+        dft<R / 2>(e);
+        dft<R / 2>(o);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            cplx t = (k == 0) ? o[k] : cmul(o[k], w16(k * (16 / R)));
+            v[k] = e[k] + t;
+            v[k + R / 2] = e[k] - t;
+        }
+    }
+}
+
+// One Stockham pass of radix R over `batch` transforms of length N.
+// Ns = product of the radices of the earlier passes.
+template <int R>
+__global__ __launch_bounds__(256) void stockham_pass_kernel(const cplx *__restrict__ in,
+                                                            cplx *__restrict__ out, int64_t N, int64_t Ns)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = N / R;
+    if (j >= stride) return;
+    const cplx *src = in + (int64_t)blockIdx.y * N;
+    cplx *dst = out + (int64_t)blockIdx.y * N;
+    const int64_t k = j & (Ns - 1);   // Ns is a power of two
+    cplx v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = src[j + r * stride];
+    if (Ns > 1) {
+        // w = exp(-2 pi i k / (Ns R)); k / (Ns R) is exact (power-of-two denominator)
+        double x = -(double)k / (double)(Ns * R);
+        x -= rint(x);
+        cplx w[R];
+        w[1] = expi_cycles(x);
+#pragma unroll
+        for (int r = 2; r < R; ++r) w[r] = cmul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = cmul(v[r], w[r]);
+    }
+    dft<R>(v);
+    const int64_t j0 = (j - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) dst[j0 + r * Ns] = v[r];
+}
+
+// Complex forward FFT of `batch` series of power-of-two length N >= 2.
+// Returns the buffer (a or b) that holds the result.
+cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
+{
+    int lg = 0;
+    while (((int64_t)1 << lg) < N) ++lg;
+    int64_t Ns = 1;
+    cplx *src = a, *dst = b;
+    auto launch = [&](int R) {
+        dim3 grid((unsigned)ceil_div(N / R, 256), (unsigned)batch);
+        switch (R) {
+        case 16:
+            hipLaunchKernelGGL(stockham_pass_kernel<16>, grid, dim3(256), 0, st, (const cplx *)src, dst, N, Ns);
+            break;
+        case 8:
+            hipLaunchKernelGGL(stockham_pass_kernel<8>, grid, dim3(256), 0, st, (const cplx *)src, dst, N, Ns);
+            break;
+        case 4:
+            hipLaunchKernelGGL(stockham_pass_kernel<4>, grid, dim3(256), 0, st, (const cplx *)src, dst, N, Ns);
+            break;
+        default:
+            hipLaunchKernelGGL(stockham_pass_kernel<2>, grid, dim3(256), 0, st, (const cplx *)src, dst, N, Ns);
+            break;
+        }
+        Ns *= R;
+        cplx *t = src;
+        src = dst;
+        dst = t;
+    };
+    // the odd-sized pass goes first (Ns = 1: no twiddles)
+    int rem = lg % 4;
+    if (rem) launch(1 << rem);
+    for (int p = 0; p < lg / 4; ++p) launch(16);
+    return src;
+}
+
+// ---- packing real series into the complex input ---------------------------
+
+// z[n] = x[2n] + i x[2n+1] for a series x of n_in samples zero-padded to 2N.
+// kind selects the series built on the fly from the per-bin moments.
+enum Series { SER_PLAIN = 0, SER_DIFF = 1 };
+
+struct PackArgs {
+    const double *a;   // plain: x = a ; diff: x = a - b
+    const double *b;
+    int64_t n_in;      // samples available
+    int64_t fold;      // 0, or the length at which the series is wrapped (x[n] + x[n + fold])
+};
+
+__device__ __forceinline__ double series_at(const PackArgs &p, int64_t i)
+{
+    if (i >= p.n_in) return 0.0;
+    double v = p.a[i];
+    if (p.b) v -= p.b[i];
+    return v;
+}
+
+__device__ __forceinline__ double series_folded(const PackArgs &p, int64_t i)
+{
+    double v = series_at(p, i);
+    if (p.fold > 0)
+        for (int64_t q = i + p.fold; q < p.n_in; q += p.fold) v += series_at(p, q);
+    return v;
+}
+
+struct PackBatch {
+    PackArgs s[3];
+};
+
+__global__ void pack_kernel(PackBatch pb, int64_t N, cplx *z)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const PackArgs &p = pb.s[blockIdx.y];
+    z[(int64_t)blockIdx.y * N + n] = cplx{series_folded(p, 2 * n), series_folded(p, 2 * n + 1)};
+}
+
+// X[k] of the real transform of length 2N from the packed transform Z (length N)
+__device__ __forceinline__ cplx unpack_bin(const cplx *Z, int64_t N, int64_t k)
+{
+    cplx zk = Z[k == N ? 0 : k];
+    cplx zn = Z[k == 0 ? 0 : N - k];
+    cplx e = cplx{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};     // (Z[k] + conj Z[N-k]) / 2
+    cplx o = cplx{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};    // (Z[k] - conj Z[N-k]) / (2i)
+    double x = -(double)k / (double)(2 * N);
+    x -= rint(x);
+    cplx w = expi_cycles(x);
+    return e + cmul(w, o);
+}
+
+__global__ void unpack_kernel(const cplx *Z, int64_t N, int64_t nout, cplx *X)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nout) return;
+    X[k] = unpack_bin(Z, N, k);
+}
+
+// ---- power_spectrum_fft epilogue (core.py:2683-2741) -----------------------
+// Z1: packed transforms of (W-S), (Wb-B), length N1 = l/2 each.
+// Z2: packed transforms of WW, WbWb, W-WW folded to length l/2, length N2 = l/4 each.
+__global__ void ps_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx *Z2, int64_t N2, int64_t nk,
+                                   double *p0, double *p1, double *pb, double *amps)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    cplx f1 = unpack_bin(Z1, N1, k);
+    cplx f2 = unpack_bin(Z1 + N1, N1, k);
+    double WmS_cos = f1.x, WmS_sin = -f1.y;
+    double WbmB_cos = f2.x, WbmB_sin = -f2.y;
+    // zero-frequency bins of the three second-moment series
+    double S2 = unpack_bin(Z2, N2, 0).x;
+    double B2 = unpack_bin(Z2 + N2, N2, 0).x;
+    double SB = unpack_bin(Z2 + 2 * N2, N2, 0).x;
+    double g3 = unpack_bin(Z2, N2, k).x;            // Re rfft(WW)[2k]
+    double g4 = unpack_bin(Z2 + N2, N2, k).x;       // Re rfft(WbWb)[2k]
+    double g5 = unpack_bin(Z2 + 2 * N2, N2, k).x;   // Re rfft(W-WW)[2k]
+    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
+    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
+    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
+    if (k == 0) {
+        WW_sin = 1.;
+        WbWb_sin = 1.;
+    }
+    double a_cos0 = WmS_cos / WW_cos;
+    double a_sin0 = WmS_sin / WW_sin;
+    double b_cos0 = WbmB_cos / WbWb_cos;
+    double b_sin0 = WbmB_sin / WbWb_sin;
+    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
+    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
+    if (k == 0) den_sin = 0.;
+    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
+    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
+    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
+    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
+    if (amps) {
+        amps[0 * nk + k] = a_cos;
+        amps[1 * nk + k] = a_sin;
+        amps[2 * nk + k] = b_cos;
+        amps[3 * nk + k] = b_sin;
+        amps[4 * nk + k] = a_cos0;
+        amps[5 * nk + k] = a_sin0;
+        amps[6 * nk + k] = b_cos0;
+        amps[7 * nk + k] = b_sin0;
+    }
+    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
+    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
+    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
+    if (p0) p0[k] = dl_nobg;
+    if (p1) p1[k] = dl - dl_null;
+    if (pb) pb[k] = dl_null;
+}
+
+// power_spectrum_simple epilogue (core.py:2766-2782)
+__global__ void ps_simple_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx *Z2, int64_t N2, int64_t nk,
+                                          double *dlogl, double *moments)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    cplx f1 = unpack_bin(Z1, N1, k);
+    double c = f1.x, s = -f1.y;
+    double S2 = unpack_bin(Z2, N2, 0).x;
+    double g = unpack_bin(Z2, N2, k).x;
+    double cc = 0.5 * (S2 + g), ss = 0.5 * (S2 - g);
+    if (k == 0) ss = 1.;
+    if (dlogl) dlogl[k] = c * c / cc + s * s / ss;
+    if (moments) {
+        moments[0 * nk + k] = c;
+        moments[1 * nk + k] = s;
+        moments[2 * nk + k] = cc;
+        moments[3 * nk + k] = ss;
+    }
+}
+
+inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}   // namespace
+
+extern "C" size_t godot_rfft_workspace_bytes(int64_t l)
+{
+    if (l < 4) return 0;
+    return 2 * align256(sizeof(cplx) * (size_t)(l / 2));
+}
+
+extern "C" int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out, void *workspace,
+                              size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0 && l >= 4, GODOT_E_INVALID, "godot_rfft_f64: need n >= 0 and l >= 4");
+    GODOT_REQUIRE(is_pow2(l), GODOT_E_UNSUPPORTED, "godot_rfft_f64: l must be a power of two");
+    GODOT_REQUIRE((x || n == 0) && out, GODOT_E_INVALID, "godot_rfft_f64: null argument");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_rfft_workspace_bytes(l), GODOT_E_WORKSPACE,
+                  "godot_rfft_f64: workspace smaller than godot_rfft_workspace_bytes(l)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = l / 2;
+    cplx *a = (cplx *)workspace;
+    cplx *b = (cplx *)((char *)workspace + align256(sizeof(cplx) * (size_t)N));
+    PackBatch pb{};
+    pb.s[0] = PackArgs{x, nullptr, n < l ? n : l, 0};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N, 256), 1), dim3(256), 0, st, pb, N, a);
+    cplx *Z = fft_c2c(a, b, N, 1, st);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)ceil_div(N + 1, 256)), dim3(256), 0, st, (const cplx *)Z, N,
+                       N + 1, (cplx *)out);
+    GODOT_LAUNCH_CHECK("godot_rfft_f64");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_power_spectrum_workspace_bytes(int64_t l)
+{
+    if (l < 8) return 0;
+    size_t N1 = (size_t)l / 2, N2 = (size_t)l / 4;
+    return 2 * align256(sizeof(cplx) * 2 * N1) + 2 * align256(sizeof(cplx) * 3 * N2);
+}
+
+extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const double *S, const double *Wb,
+                                        const double *WbWb, const double *B, int64_t n, int64_t l, double *p0,
+                                        double *p1, double *pb, double *amps, void *workspace,
+                                        size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 1 && l >= 8, GODOT_E_INVALID, "godot_power_spectrum_fft: need n >= 1 and l >= 8");
+    GODOT_REQUIRE(is_pow2(l), GODOT_E_UNSUPPORTED,
+                  "godot_power_spectrum_fft: the padded length l must be a power of two");
+    GODOT_REQUIRE(n <= l, GODOT_E_INVALID, "godot_power_spectrum_fft: n exceeds the padded length");
+    GODOT_REQUIRE(W && WW && S && Wb && WbWb && B, GODOT_E_INVALID, "godot_power_spectrum_fft: null series");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_power_spectrum_workspace_bytes(l), GODOT_E_WORKSPACE,
+                  "godot_power_spectrum_fft: workspace smaller than godot_power_spectrum_workspace_bytes(l)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N1 = l / 2, N2 = l / 4, nk = l / 4 + 1;
+    char *ws = (char *)workspace;
+    size_t sz1 = align256(sizeof(cplx) * 2 * (size_t)N1), sz2 = align256(sizeof(cplx) * 3 * (size_t)N2);
+    cplx *a1 = (cplx *)ws, *b1 = (cplx *)(ws + sz1);
+    cplx *a2 = (cplx *)(ws + 2 * sz1), *b2 = (cplx *)(ws + 2 * sz1 + sz2);
+    // second-moment series: only the even bins of their length-l transforms are
+    // used, which are the bins of the length-l/2 transform of the series wrapped at l/2
+    PackBatch pb2{};
+    pb2.s[0] = PackArgs{WW, nullptr, n, l / 2};
+    pb2.s[1] = PackArgs{WbWb, nullptr, n, l / 2};
+    pb2.s[2] = PackArgs{W, WW, n, l / 2};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N2, 256), 3), dim3(256), 0, st, pb2, N2, a2);
+    cplx *Z2 = fft_c2c(a2, b2, N2, 3, st);
+    PackBatch pb1{};
+    pb1.s[0] = PackArgs{W, S, n, 0};
+    pb1.s[1] = PackArgs{Wb, B, n, 0};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N1, 256), 2), dim3(256), 0, st, pb1, N1, a1);
+    cplx *Z1 = fft_c2c(a1, b1, N1, 2, st);
+    hipLaunchKernelGGL(ps_epilogue_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0, st, (const cplx *)Z1,
+                       N1, (const cplx *)Z2, N2, nk, p0, p1, pb, amps);
+    GODOT_LAUNCH_CHECK("godot_power_spectrum_fft");
+    return GODOT_OK;
+}
+
+extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, const double *S, int64_t n,
+                                           double *dlogl, double *moments, void *workspace,
+                                           size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 8, GODOT_E_INVALID, "godot_power_spectrum_simple: need n >= 8");
+    GODOT_REQUIRE(is_pow2(n), GODOT_E_UNSUPPORTED,
+                  "godot_power_spectrum_simple: the series length must be a power of two");
+    GODOT_REQUIRE(W && WW && S, GODOT_E_INVALID, "godot_power_spectrum_simple: null series");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_power_spectrum_workspace_bytes(n), GODOT_E_WORKSPACE,
+                  "godot_power_spectrum_simple: workspace smaller than godot_power_spectrum_workspace_bytes(n)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t l = n, N1 = l / 2, N2 = l / 4, nk = l / 4 + 1;
+    char *ws = (char *)workspace;
+    size_t sz1 = align256(sizeof(cplx) * 2 * (size_t)N1), sz2 = align256(sizeof(cplx) * 3 * (size_t)N2);
+    cplx *a1 = (cplx *)ws, *b1 = (cplx *)(ws + sz1);
+    cplx *a2 = (cplx *)(ws + 2 * sz1), *b2 = (cplx *)(ws + 2 * sz1 + sz2);
+    PackBatch pb2{};
+    pb2.s[0] = PackArgs{WW, nullptr, n, l / 2};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N2, 256), 1), dim3(256), 0, st, pb2, N2, a2);
+    cplx *Z2 = fft_c2c(a2, b2, N2, 1, st);
+    PackBatch pb1{};
+    pb1.s[0] = PackArgs{W, S, n, 0};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N1, 256), 1), dim3(256), 0, st, pb1, N1, a1);
+    cplx *Z1 = fft_c2c(a1, b1, N1, 1, st);
+    hipLaunchKernelGGL(ps_simple_epilogue_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0, st,
+                       (const cplx *)Z1, N1, (const cplx *)Z2, N2, nk, dlogl, moments);
+    GODOT_LAUNCH_CHECK("godot_power_spectrum_simple");
+    return GODOT_OK;
+}

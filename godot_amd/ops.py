@@ -243,3 +243,88 @@ def gather(src, idx):
     with torch.cuda.device(dev):
         _lib.call(name, _p(src), _p(idx), n, _p(dst), _stream(dev))
     return dst
+
+
+# ---------------------------------------------------------------------------
+# power spectra and trig sums
+# ---------------------------------------------------------------------------
+def rfft(x, l):
+    """numpy.fft.rfft(x, n=l) for a power-of-two l: (l/2+1, 2) tensor of (re, im)."""
+    _dev_check(x, F64, 'x')
+    dev = x.device
+    out = torch.empty((l // 2 + 1, 2), dtype=F64, device=dev)
+    ws = _workspace(_lib.lib.godot_rfft_workspace_bytes(l), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_rfft_f64', _p(x), x.numel(), l, _p(out), _p(ws), ws.numel(), _stream(dev))
+    return out
+
+
+def power_spectrum_fft(W, WW, S, Wb, WbWb, B, l, want_amps=False):
+    for t, nm in ((W, 'W'), (WW, 'WW'), (S, 'S'), (Wb, 'Wb'), (WbWb, 'WbWb'), (B, 'B')):
+        _dev_check(t, F64, nm)
+        if t.numel() != W.numel():
+            raise ValueError('the six series must have equal lengths')
+    n, dev = W.numel(), W.device
+    nk = l // 4 + 1
+    p0 = torch.empty(nk, dtype=F64, device=dev)
+    p1 = torch.empty(nk, dtype=F64, device=dev)
+    pb = torch.empty(nk, dtype=F64, device=dev)
+    amps = torch.empty((8, nk), dtype=F64, device=dev) if want_amps else None
+    ws = _workspace(_lib.lib.godot_power_spectrum_workspace_bytes(l), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_power_spectrum_fft', _p(W), _p(WW), _p(S), _p(Wb), _p(WbWb), _p(B), n, l,
+                  _p(p0), _p(p1), _p(pb), _p(amps), _p(ws), ws.numel(), _stream(dev))
+    return p0, p1, pb, amps
+
+
+def power_spectrum_simple(W, WW, S, want_moments=False):
+    for t, nm in ((W, 'W'), (WW, 'WW'), (S, 'S')):
+        _dev_check(t, F64, nm)
+    n, dev = W.numel(), W.device
+    nk = n // 4 + 1
+    dl = torch.empty(nk, dtype=F64, device=dev)
+    mom = torch.empty((4, nk), dtype=F64, device=dev) if want_moments else None
+    ws = _workspace(_lib.lib.godot_power_spectrum_workspace_bytes(n), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_power_spectrum_simple', _p(W), _p(WW), _p(S), n, _p(dl), _p(mom), _p(ws),
+                  ws.numel(), _stream(dev))
+    return dl, mom
+
+
+def trigsum_cells(w1, w2, exp, tmid, freqs, exp_scale=1.0):
+    for t, nm in ((w1, 'w1'), (w2, 'w2'), (exp, 'exp'), (tmid, 'tmid'), (freqs, 'freqs')):
+        _dev_check(t, F64, nm)
+    dev = w1.device
+    out = torch.empty(freqs.numel(), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_trigsum_cells', _p(w1), _p(w2), _p(exp), _p(tmid), w1.numel(), _p(freqs),
+                  freqs.numel(), float(exp_scale), _p(out), _stream(dev))
+    return out
+
+
+def fit_harmonics(w1, w2, exp, tmid, tmean, freqs):
+    for t, nm in ((w1, 'w1'), (w2, 'w2'), (exp, 'exp'), (tmid, 'tmid'), (freqs, 'freqs')):
+        _dev_check(t, F64, nm)
+    dev = w1.device
+    out = torch.empty((freqs.numel(), 3), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_fit_harmonics', _p(w1), _p(w2), _p(exp), _p(tmid), w1.numel(), float(tmean),
+                  _p(freqs), freqs.numel(), _p(out), _stream(dev))
+    return out
+
+
+def z2m(t, w, f0, df, nf, m=2, j0=0, want_z2=True, want_h=False, workspace=None):
+    """Weighted Z^2_m (and/or H) on the grid f0 + (j0 + j) df, j < nf."""
+    _dev_check(t, F64, 't')
+    _dev_check(w, F64, 'w')
+    if t.numel() != w.numel():
+        raise ValueError('t and w must have equal lengths')
+    dev = t.device
+    need = _lib.lib.godot_z2m_workspace_bytes(t.numel(), nf, m)
+    ws = workspace if workspace is not None else _workspace(need, dev)
+    z = torch.empty(nf, dtype=F64, device=dev) if want_z2 else None
+    h = torch.empty(nf, dtype=F64, device=dev) if want_h else None
+    with torch.cuda.device(dev):
+        _lib.call('godot_z2m', _p(t), _p(w), t.numel(), float(f0), float(df), int(j0), int(nf), int(m),
+                  _p(z), _p(h), _p(ws), ws.numel(), _stream(dev))
+    return z, h

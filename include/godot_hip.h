@@ -219,20 +219,21 @@ int godot_power_spectrum_simple(const double *W, const double *WW,
 
 /* ---- direct trig sums: core.py:2426-2596 ----------------------------------- */
 
-/* power_spectrum_dft (core.py:2540-2596): per-cell phase from the 1000-entry
- * cos/sin table, photon moments through the CSR layout.                       */
-int godot_trigsum_cells(const double *we, int64_t nph,
-        const int64_t *lo, const int64_t *hi,
-                        const double *exp, const double *tmid, int64_t ncell,
-                        const double *freqs, int64_t nfreq, int unweighted,
-                        double exp_scale, double *power,
-                        godot_stream_t stream);
+/* power_spectrum_dft (core.py:2540-2596).  Every photon of a cell shares the
+ * cell's phase, so the photon sums collapse to the per-cell moments
+ * w1 = sum(w), w2 = sum(w^2) (godot_cell_moments); for unweighted=True pass the
+ * counts as doubles for both and exp_scale = nph / sum(w) (core.py:2548-2551).
+ * The per-cell phase uses the reference's 1000-entry cos/sin table with the
+ * same truncation.  power has nfreq entries.                                  */
+int godot_trigsum_cells(const double *w1, const double *w2, const double *exp,
+                        const double *tmid, int64_t ncell,
+                        const double *freqs, int64_t nfreq, double exp_scale,
+                        double *power, godot_stream_t stream);
 
-/* fit_harmonics (core.py:2426-2488) at nfreq frequencies: out[f] =
- * {camp, samp, ts}.                                                           */
-int godot_fit_harmonics(const double *we, int64_t nph,
-        const int64_t *lo, const int64_t *hi,
-                        const double *exp, const double *tmid, int64_t ncell,
+/* fit_harmonics (core.py:2426-2488) at nfreq frequencies with exact cos/sin:
+ * out[f] = {camp, samp, ts}.  tmean = mean of tmid (core.py:2438).           */
+int godot_fit_harmonics(const double *w1, const double *w2, const double *exp,
+                        const double *tmid, int64_t ncell, double tmean,
                         const double *freqs, int64_t nfreq,
                         double *out /* [nfreq][3] */, godot_stream_t stream);
 
@@ -241,11 +242,13 @@ int godot_fit_harmonics(const double *we, int64_t nph,
  *                                      (sum_i w_i sin 2 pi k f t_i)^2].
  * No counterpart in the reference (it holds no Z^2_m / H-test routine; the
  * statistic is the photon-phase limit of fit_harmonics, core.py:2481).
- * t is relative to any epoch the caller chooses.  1 <= m <= 20.
+ * f_j is the real number f0 + (j0 + j) df (f0, df the given doubles): phases
+ * are formed from exactly reduced products, so accuracy does not degrade with
+ * t f.  t is relative to any epoch the caller chooses.  1 <= m <= 20.
  *   z2   output [nf] (Z^2_m), may be NULL
- *   h    output [nf] (H = max_k (Z^2_k - 4k + 4), k <= m), may be NULL
- * workspace: godot_z2m_workspace_bytes(nph).                                  */
-size_t godot_z2m_workspace_bytes(int64_t nph);
+ *   h    output [nf] (H = max_{k<=m} (Z^2_k - 4k + 4)), may be NULL
+ * workspace: godot_z2m_workspace_bytes(nph, nf, m).                           */
+size_t godot_z2m_workspace_bytes(int64_t nph, int64_t nf, int m);
 int godot_z2m(const double *t, const double *w, int64_t nph,
               double f0, double df, int64_t j0, int64_t nf, int m,
               double *z2, double *h, void *workspace, size_t workspace_bytes,

@@ -1,0 +1,160 @@
+"""GPU parity of the FFT power spectra, the direct trig sums and the Z^2_m
+search against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import godot_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _n(t):
+    return t.cpu().numpy()
+
+
+def _ts(g):
+    from godot_amd import core
+    d = torch.device(DEV)
+    f = lambda k, dt=torch.float64: torch.from_numpy(np.array(g[k])).to(device=d, dtype=dt)
+    return core.CellTimeSeries(f('starts'), f('stops'), f('exp'), f('sexp'), f('bexp'),
+                               f('counts', torch.int64), f('weights'), f('weights2'), f('deadtime'),
+                               timesys='topocentric', minimum_exposure=0)
+
+
+@pytest.mark.parametrize('l,n', [(4, 3), (8, 8), (16, 5), (32, 32), (64, 33), (256, 256), (1024, 700),
+                                 (4096, 4096), (1 << 13, 5000), (1 << 16, 1 << 16), (1 << 17, 99999),
+                                 (1 << 20, 300000)])
+def test_rfft_matches_numpy(l, n):
+    from godot_amd import ops
+    rng = np.random.default_rng(l + n)
+    x = rng.normal(size=n) * rng.uniform(0.1, 10)
+    out = _n(ops.rfft(torch.from_numpy(x).to(DEV), l))
+    ref = np.fft.rfft(x, n=l)
+    tol = 1e-9 * np.abs(ref).max()      # the bar: abs <= 1e-9 max|X|
+    assert np.abs(out[:, 0] - ref.real).max() <= tol and np.abs(out[:, 1] - ref.imag).max() <= tol
+    # in practice far tighter
+    assert np.abs(out[:, 0] + 1j * out[:, 1] - ref).max() <= 1e-13 * np.abs(ref).max() * np.log2(l)
+
+
+def test_rfft_linearity_and_impulse():
+    from godot_amd import ops
+    l = 1 << 18
+    x = torch.zeros(l, dtype=torch.float64, device=DEV)
+    x[1] = 1.0
+    out = _n(ops.rfft(x, l))
+    k = np.arange(l // 2 + 1)
+    assert np.abs(out[:, 0] - np.cos(2 * np.pi * k / l)).max() < 1e-14
+    assert np.abs(out[:, 1] + np.sin(2 * np.pi * k / l)).max() < 1e-14
+
+
+def _rel(a, b, floor):
+    return np.abs(a - b) <= 1e-9 * np.maximum(np.abs(b), floor)
+
+
+def test_power_spectrum_fft_matches_reference(golden):
+    from godot_amd import core
+    g = golden('timeseries_fft.npz')
+    ts = _ts(g)
+    f, p0, p1, pb = core.power_spectrum_fft(ts)
+    assert np.array_equal(f, g['ps_freqs'])
+    for got, key in ((p0, 'ps_p0'), (p1, 'ps_p1'), (pb, 'ps_pb')):
+        ref = g[key]
+        ok = _rel(got, ref, floor=np.nanmax(np.abs(ref)) * 1e-6) | (np.isnan(got) & np.isnan(ref))
+        assert ok.all(), (key, np.argwhere(~ok)[:5].ravel(), got[~ok][:5], ref[~ok][:5])
+    amps = core.power_spectrum_fft(ts, get_amps=True)
+    for i in range(8):
+        ref = g['ps_amps'][i]
+        got = amps[1 + i]
+        ok = _rel(got, ref, floor=np.nanmax(np.abs(ref[np.isfinite(ref)])) * 1e-6) \
+            | (~np.isfinite(ref) & ~np.isfinite(got))
+        assert ok.all(), (i, np.argwhere(~ok)[:5].ravel(), got[~ok][:5], ref[~ok][:5])
+    tw = core.power_spectrum_fft(ts, tweak_exp=True)
+    for i in range(3):
+        ref = g['ps_tweak'][i]
+        assert _rel(tw[1 + i], ref, floor=np.abs(ref).max() * 1e-6).all(), i
+    eo = core.power_spectrum_fft(ts, exp_only=True)
+    assert _rel(eo[1], g['ps_exp_only'], floor=np.abs(g['ps_exp_only']).max() * 1e-6).all()
+
+
+def test_power_spectrum_simple_matches_reference(golden):
+    from godot_amd import core
+    g = golden('timeseries_fft.npz')
+    n = int(g['pss2_n'])
+    ts = _ts({k: (g[k][:n] if k in ('starts', 'stops', 'exp', 'sexp', 'bexp', 'counts', 'weights',
+                                    'weights2', 'deadtime') else g[k]) for k in g})
+    f, dl = core.power_spectrum_simple(ts)
+    assert np.array_equal(f, g['pss2_freqs'])
+    ref = g['pss2_dlogl']
+    assert _rel(dl, ref, floor=np.abs(ref).max() * 1e-6).all()
+    # non power-of-two lengths are refused loudly, not approximated
+    with pytest.raises(NotImplementedError):
+        core.power_spectrum_simple(_ts(g))
+
+
+def test_trig_sums_match_reference(golden):
+    from godot_amd import core, ops
+    g = golden('trig_sums.npz')
+    d = torch.device(DEV)
+    off = np.append(0, np.cumsum(g['counts'])).astype(np.int64)
+    offd = torch.from_numpy(off).to(d)
+    batch = core.CellBatch(torch.from_numpy(g['we']).to(d), torch.from_numpy(g['we']).to(d), offd[:-1],
+                           offd[1:], torch.from_numpy(g['starts']).to(d),
+                           torch.from_numpy(g['stops']).to(d), torch.from_numpy(g['exp']).to(d),
+                           torch.from_numpy(g['exp'] * 5).to(d))
+    old = core.CellsLogLikelihoodOld(batch)
+    assert old.nph == len(g['we'])
+    got = core.power_spectrum_dft(old, g['freqs'])
+    assert _rel(got, g['dft'], floor=np.abs(g['dft']).max() * 1e-6).all()
+    got = core.power_spectrum_dft(old, g['freqs'], unweighted=True)
+    assert _rel(got, g['dft_unweighted'], floor=np.abs(g['dft_unweighted']).max() * 1e-6).all()
+    fh = core.fit_harmonics(old, g['freqs'][:16])
+    ref = g['harmonics']
+    assert _rel(fh, ref, floor=np.abs(ref).max(axis=0, keepdims=True) * 1e-6).all()
+    c, s, t = core.fit_harmonics(old, float(g['freqs'][3]))
+    assert _rel(np.array([c, s, t]), ref[3], floor=np.abs(ref).max(axis=0) * 1e-6).all()
+
+
+@pytest.mark.parametrize('m', [1, 2, 3, 4, 7, 10, 20])
+def test_z2m_matches_oracle(m):
+    from godot_amd import ops
+    rng = np.random.default_rng(m)
+    nph = 5000
+    t = np.sort(rng.uniform(0, 3.2e8, nph))
+    w = np.clip(rng.beta(0.3, 1.5, nph), 1e-6, 1 - 1e-6)
+    f0, df, nf, j0 = 2.5e-3, 6.1e-10, 300, 123456
+    z, h = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=m, j0=j0,
+                   want_h=True)
+    ref = orc.z2m(t, w, f0, df, nf, m=m, j0=j0)
+    assert np.abs(_n(z) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    href = orc.h_test(t, w, f0, df, nf, mmax=m, j0=j0)
+    assert np.abs(_n(h) - href).max() <= 1e-12 * max(1.0, np.abs(href).max())
+
+
+def test_z2m_signal_and_exactness_at_large_phase():
+    """A pulsed signal is recovered at its frequency after 1e10 cycles; the
+    single-launch and photon-split paths agree."""
+    from godot_amd import ops
+    rng = np.random.default_rng(9)
+    nph = 20000
+    fsig = 31.41592653589793
+    t = np.sort(rng.uniform(0, 3.0e8, nph))
+    # pulsed: keep photons near phase 0
+    ph = (t * fsig) % 1.0
+    keep = rng.random(nph) < 0.5 * (1 + np.cos(2 * np.pi * ph))
+    t = t[keep]
+    w = np.full(len(t), 0.7)
+    df = 1e-10
+    f0 = fsig - 50 * df
+    z, _ = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, 101, m=2)
+    z = _n(z)
+    assert np.argmax(z) in (49, 50, 51) and z.max() > 1000
+    ze = orc.z2m_exact(t[:300], w[:300], f0, df, 50, 2)
+    z3, _ = ops.z2m(torch.from_numpy(t[:300].copy()).to(DEV), torch.from_numpy(w[:300].copy()).to(DEV),
+                    f0, df, 51, m=2)
+    assert abs(_n(z3)[50] - ze) <= 1e-9 * max(1, ze)
+    # many frequencies -> one launch over all photons; must equal the split path
+    nf = 256 * 16 * 1100
+    zbig, _ = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=2)
+    assert np.abs(_n(zbig[:101]) - z).max() <= 1e-9 * z.max()
