@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Benchmark of the weighted-photon likelihood hot path on MI355X.
+
+One "step" = one batched maximum-likelihood fit (alpha-hat + TS, the
+reference's get_max + get_ts) of every cell of the workload
+    C2: 1e7 synthetic photons, 10 yr, 10-minute cells (zero-exposure cells
+        trimmed), cells built by the GPU binning path,
+with all inputs resident in HBM.  Weak scaling: every rank owns one such
+photon list (seed 11 + rank); results are gathered once over RCCL at the end
+of the timed region.  Rank 0 prints one JSON line.
+
+Also reported (rank 0, "extra"): the 200-point profile-grid rate on the same
+cells, the Z^2_2 search rate (photon x frequency evaluations per second), the
+power_spectrum_fft time at the C3 size (3 786 912 bins -> l = 2^25), the
+one-off binning time, and the CPU baseline: the numpy oracle (a restatement
+of the reference's per-cell Python path) timed on one host core on a bounded
+sample of the same cells.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--nph', type=int, default=10_000_000)
+    ap.add_argument('--years', type=float, default=10.0)
+    ap.add_argument('--tcell', type=float, default=600.0)
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra measurements')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, stream):
+    """Average device time of fn() over iters launches, HIP events on `stream`."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(iters)]
+    for a, b in evs:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def cpu_baseline(s, tcell, seconds):
+    """The oracle's per-cell get_max + get_ts on one core, bounded in time."""
+    from oracle import godot_oracle as orc
+    # bin a leading slice of the same photon list (binning itself is not timed)
+    t_end = s['TSTART'][0] + 40 * 86400.
+    m = s['ti'] < t_end
+    r = s['TSTOP'] <= t_end
+    b = orc.bin_cells(s['ti'][m], s['we'][m], s['TSTART'][r], s['TSTOP'][r], s['exposure'][r],
+                      s['LIVETIME'][r], s['S'], s['B'], s['E'], tcell=tcell)
+    clls = orc.cells_from_bins(b)
+    n = 0
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        while True:
+            for c in clls:
+                a = c.get_max()
+                c.get_ts(a)
+                n += 1
+            if time.perf_counter() - t0 > seconds:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit='cells/s', cores=1, kind='port',
+                sample='oracle get_max+get_ts over the first %d cells (40 days) of the same '
+                       'workload, repeated for %.0f s on one core' % (len(clls), dt))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.current_stream(dev)
+
+    from godot_amd import core, ops, synth
+
+    # ---- workload: C2, one photon list per rank ---------------------------------
+    s = synth.synth(args.nph, years=args.years, seed=11 + rank)
+    data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'],
+                     device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+    torch.cuda.synchronize()
+    t_bin_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+    torch.cuda.synchronize()
+    t_bin_again = time.perf_counter() - t0
+    cr = cells.ranges()
+    ncell = cr.ncell
+    nph_in = int((cr.hi - cr.lo).sum().cpu())
+
+    def step():
+        return ops.cell_fit(cr)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    if dist is not None:
+        # the job's result: per-cell (alpha, TS) records of all ranks, gathered once
+        rec = torch.stack([out[0], out[1]], dim=1)
+        nmax = torch.tensor([ncell], device=dev)
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+        pad = torch.zeros((int(nmax.item()), 2), dtype=rec.dtype, device=dev)
+        pad[:ncell] = rec
+        gathered = torch.empty((world,) + tuple(pad.shape), dtype=rec.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, pad)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(ncell)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].cpu())
+    total_cells = float(tot[1].cpu())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (cell_fit), HIP events on its stream -----
+    k_ms = event_time_ms(step, max(20, min(args.steps, 200)), stream)
+    alg_bytes = 8 * nph_in + 8 * (ncell + 1) + 16 * ncell + 16 * ncell
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=achieved / HBM_PEAK_GBS, traffic=None, kernel='cell_fit_kernel',
+                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=k_ms)
+
+    extra = dict(ncell=ncell, photons_in_cells=nph_in,
+                 binning_first_call_s=t_bin_first, binning_cached_table_s=t_bin_again)
+    if not args.no_extra:
+        # 200-point profile grid on the same cells (FP64-ALU bound)
+        ops.cell_logpdf(cr, dlogl=30, npt=200)
+        p_ms = event_time_ms(lambda: ops.cell_logpdf(cr, dlogl=30, npt=200), 5, stream)
+        extra['profile_grid'] = dict(cells_per_s=ncell / (p_ms * 1e-3), ms=p_ms,
+                                     log_evals_per_s=200.0 * nph_in / (p_ms * 1e-3))
+        torch.cuda.empty_cache()
+        # Z^2_2 search: 1e6 photons x 2^21 trial frequencies (a slice of C4's 1e8)
+        zs = synth.synth(1_000_000, years=1.0, seed=17)
+        zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
+        zw = torch.from_numpy(zs['we']).to(dev)
+        nf = 1 << 21
+        span = float(zs['ti'][-1] - zs['ti'][0])
+        f0, df = 1e-4, 1.0 / (4 * span)
+        ws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), nf, 2), dtype=torch.uint8,
+                         device=dev)
+        ops.z2m(zt, zw, f0, df, nf, m=2, workspace=ws)
+        z_ms = event_time_ms(lambda: ops.z2m(zt, zw, f0, df, nf, m=2, workspace=ws), 3, stream)
+        evals = float(zt.numel()) * nf / (z_ms * 1e-3)
+        extra['z2m'] = dict(photon_freq_evals_per_s=evals, ms=z_ms, nph=zt.numel(), nfreq=nf, m=2,
+                            nominal_flops_per_eval=45, executed_flops_per_eval=19,
+                            nominal_frac_of_fp64_peak=45 * evals / (FP64_PEAK_TFLOPS * 1e12),
+                            executed_frac_of_fp64_peak=19 * evals / (FP64_PEAK_TFLOPS * 1e12))
+        del ws
+        torch.cuda.empty_cache()
+        # power_spectrum_fft at the C3 size: 3 786 912 bins of 100 s -> l = 2^25
+        nb = 3_786_912
+        g = torch.Generator(device=dev)
+        g.manual_seed(13)
+        cnt = torch.poisson(torch.full((nb,), 2.6, dtype=torch.float64, device=dev), generator=g)
+        W = cnt * 0.17
+        WW = cnt * 0.08
+        S = torch.full((nb,), 0.44, dtype=torch.float64, device=dev)
+        B = S * 5
+        l = 1 << 25
+        ops.power_spectrum_fft(W, WW, S, cnt - W, cnt - 2 * W + WW, B, l)
+        f_ms = event_time_ms(lambda: ops.power_spectrum_fft(W, WW, S, cnt - W, cnt - 2 * W + WW, B, l),
+                             3, stream)
+        extra['power_spectrum_fft'] = dict(ms=f_ms, nbins=nb, l=l)
+        torch.cuda.empty_cache()
+
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(s, args.tcell, args.cpu_seconds)
+
+    line = {
+        'metric': 'cells fit/s + photon×freq evals/s (1/2/4/8 GPU), % HBM/FP64 roofline',
+        'value': total_cells * args.steps / elapsed,
+        'unit': 'cells/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': 'C2: %.0e photons, %g yr, %g-s cells (%d cells per GPU after '
+                               'trimming), batched alpha-hat + TS fit' % (
+                                   args.nph, args.years, args.tcell, ncell),
+                   'parallelism': 'one photon list per GPU; results all-gathered once'},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+        'extra': extra,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
