@@ -7,7 +7,9 @@
 // the fixed-schedule Newton/Halley maximiser, the TS and the support search
 // out of registers; per-pass sums are combined with wavefront butterflies.
 // Cells that do not fit T*R registers re-read their weights per pass (they
-// then come from L2, which a cell of that size still fits).
+// then come from L2, which a cell of that size still fits).  Divisions are a
+// hardware reciprocal estimate plus two Newton steps (the operands are never
+// near the ends of the exponent range), reductions use DPP lane permutes.
 #include "common.hpp"
 
 namespace {
@@ -99,7 +101,7 @@ __device__ double score(const CellData<T, R> &cd, double a, double b, double S)
     double acc[1];
     cd.template sums<1>([=](double w, double (&s)[1]) {
         double t2 = 1.0 + b * (1.0 - w);
-        s[0] += w / (t2 + a * w);
+        s[0] += w * rcp_fast(t2 + a * w);
     }, acc);
     return acc[0] - S;
 }
@@ -173,6 +175,97 @@ __device__ double max_numerical(const CellData<T, R> &cd, double S, int &flags)
     return qnan();
 }
 
+template <int T, int R, bool B0>
+__device__ bool fit_attempt_impl(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
+                                 bool &at_zero);
+
+// One pass of the fixed schedule (core.py:639-680) from the zero-based start
+// values g = guess - 1, b = beta - 1.  Returns true when the result `a` (zero-
+// based) is final, false when the reference would call itself again with
+// guess = a + 1 (core.py:684-689).
+template <int T, int R>
+__device__ bool fit_attempt(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
+                            bool &at_zero)
+{
+    // background level fixed at its nominal value (beta = 1): t2 = 1 exactly
+    if (b == 0.0) return fit_attempt_impl<T, R, true>(cd, S, g, 0.0, a_out, at_zero);
+    return fit_attempt_impl<T, R, false>(cd, S, g, b, a_out, at_zero);
+}
+
+
+template <int T, int R, bool B0>
+__device__ bool fit_attempt_impl(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
+                                 bool &at_zero)
+{
+    double acc[3];
+    at_zero = false;
+    // t2 = 1 + b (1 - w)
+    auto t2of = [=](double w) { return B0 ? 1.0 : 1.0 + b * (1.0 - w); };
+    // derivative at alpha = 0 (core.py:639-644) fused with the sums of the
+    // first Newton step when that starts from a = 0, b = 0 (w / 1 = w exactly)
+    double a = g;
+    if (B0 && g == 0.0) {
+        cd.template sums<3>([](double w, double (&s)[3]) {
+            s[0] += w * rcp_fast(1.0 - w);
+            s[1] += w;
+            s[2] += w * w;
+        }, acc);
+        if (acc[0] - S < 0) {
+            at_zero = true;
+            a_out = -1.0;
+            return true;
+        }
+        a = a + (acc[1] - S) * rcp_fast(acc[2]);
+    } else {
+        if (score(cd, -1.0, b, S) < 0) {
+            at_zero = true;
+            a_out = -1.0;
+            return true;
+        }
+        cd.template sums<2>([=](double w, double (&s)[2]) {
+            double r = w * rcp_fast(fma(g, w, t2of(w)));
+            s[0] += r;
+            s[1] += r * r;
+        }, reinterpret_cast<double (&)[2]>(acc));
+        a = a + (acc[0] - S) * rcp_fast(acc[1]);
+    }
+    // Newton 1 keeps away from zero flux (core.py:653-655)
+    if (a < 0 - 1) a = 0.2 - 1;
+    auto pass2 = [&](double a_) {
+        cd.template sums<2>([=](double w, double (&s)[2]) {
+            double r = w * rcp_fast(fma(a_, w, t2of(w)));
+            s[0] += r;
+            s[1] += r * r;
+        }, reinterpret_cast<double (&)[2]>(acc));
+    };
+    // Newton 2 (core.py:658-664)
+    pass2(a);
+    a = a + (acc[0] - S) * rcp_fast(acc[1]);
+    if (a < 0.05 - 1) a = 0.05 - 1;
+    // Newton 3 (core.py:667-671)
+    pass2(a);
+    a = pymax(0.0 - 1, a + (acc[0] - S) * rcp_fast(acc[1]));
+    double alast = a;
+    // Halley (core.py:674-680)
+    {
+        double a_ = a;
+        cd.template sums<3>([=](double w, double (&s)[3]) {
+            double r = w * rcp_fast(fma(a_, w, t2of(w)));
+            double r2 = r * r;
+            s[0] += r;
+            s[1] += r2;
+            s[2] += r2 * r;
+        }, acc);
+    }
+    double f1 = acc[0] - S, f2 = acc[1], f3 = 2 * acc[2];
+    a = pymax(0.0 - 1, a + 2 * f1 * f2 * rcp_fast(2 * f2 * f2 - f1 * f3));
+    a_out = a;
+    // slow convergence or a far-away start: the reference tries again
+    return !((fabs(a - alast) > 0.05) || (fabs(g - a) > 10));
+}
+
+// get_max in place: used where a cell's weights are already loaded and no
+// other team can take over its restarts (the profile-grid kernel).
 template <int T, int R>
 __device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, double beta, int &flags)
 {
@@ -180,57 +273,18 @@ __device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, do
     double b = beta - 1;
     for (int depth = 0;; ++depth) {
         flags = (flags & ~GODOT_F_DEPTH_MASK) | (depth << 1);
-        // derivative at alpha = 0 (core.py:639-644)
-        if (score(cd, -1.0, b, S) < 0) {
-            flags |= GODOT_F_AT_ZERO;
-            return 0.0;
+        double a;
+        bool at_zero;
+        if (fit_attempt(cd, S, g, b, a, at_zero)) {
+            if (at_zero) {
+                flags |= GODOT_F_AT_ZERO;
+                return 0.0;
+            }
+            return a + 1;
         }
-        double a = g;
-        double acc[3];
-        auto pass2 = [&](double a_) {
-            cd.template sums<2>([=](double w, double (&s)[2]) {
-                double t2 = 1.0 + b * (1.0 - w);
-                double r = w / (t2 + a_ * w);
-                s[0] += r;
-                s[1] += r * r;
-            }, reinterpret_cast<double (&)[2]>(acc));
-        };
-        // Newton 1: keep away from zero flux (core.py:649-655)
-        pass2(a);
-        a = a + (acc[0] - S) / acc[1];
-        if (a < 0 - 1) a = 0.2 - 1;
-        // Newton 2 (core.py:658-664)
-        pass2(a);
-        a = a + (acc[0] - S) / acc[1];
-        if (a < 0.05 - 1) a = 0.05 - 1;
-        // Newton 3 (core.py:667-671)
-        pass2(a);
-        a = pymax(0.0 - 1, a + (acc[0] - S) / acc[1]);
-        double alast = a;
-        // Halley (core.py:674-680)
-        {
-            double a_ = a;
-            cd.template sums<3>([=](double w, double (&s)[3]) {
-                double t2 = 1.0 + b * (1.0 - w);
-                double r = w / (t2 + a_ * w);
-                double r2 = r * r;
-                s[0] += r;
-                s[1] += r2;
-                s[2] += r2 * r;
-            }, acc);
-        }
-        {
-            double f1 = acc[0] - S, f2 = acc[1], f3 = 2 * acc[2];
-            a = pymax(0.0 - 1, a + 2 * f1 * f2 / (2 * f2 * f2 - f1 * f3));
-        }
-        // slow convergence or a far-away start: try again (core.py:684-689)
-        if ((fabs(a - alast) > 0.05) || (fabs(g - a) > 10)) {
-            if (depth > 2) return max_numerical(cd, S, flags);
-            g = (a + 1) - 1;
-            b = (b + 1) - 1;
-            continue;
-        }
-        return a + 1;
+        if (depth > 2) return max_numerical(cd, S, flags);
+        g = (a + 1) - 1;
+        b = (b + 1) - 1;
     }
 }
 
@@ -245,18 +299,50 @@ __device__ double loglike(const CellData<T, R> &cd, double S, double alpha)
     return acc[0] - S * alpha;
 }
 
-// 2 (logL(aopt) - logL(0))   (core.py:982-994)
+// 2 (logL(aopt) - logL(0))   (core.py:982-994).
+// sum_i log(t_i) is formed as the log of the product of the t_i: the running
+// product is renormalised (mantissa in [0.5, 1), exponent kept as an integer)
+// often enough that it can neither overflow nor underflow, and one logarithm
+// per cell replaces one per photon.  The difference from summing individually
+// rounded logarithms is a few ulp of the terms.
 template <int T, int R>
 __device__ double test_statistic(const CellData<T, R> &cd, double S, double aopt)
 {
     if (S == 0 || aopt == 0) return 0.0;
-    double acc[2];
-    cd.template sums<2>([=](double w, double (&s)[2]) {
-        double iw = 1.0 - w;
-        s[0] += log(w * aopt + iw);
-        s[1] += log(iw);
-    }, acc);
-    return 2 * ((acc[0] - S * aopt) - acc[1]);
+    double pt = 1.0, pi = 1.0;   // products of (aopt w + 1 - w) and of (1 - w)
+    int et = 0, ei = 0;
+    auto renorm = [&]() {
+        et += __builtin_amdgcn_frexp_exp(pt);
+        pt = __builtin_amdgcn_frexp_mant(pt);
+        ei += __builtin_amdgcn_frexp_exp(pi);
+        pi = __builtin_amdgcn_frexp_mant(pi);
+    };
+    if (cd.in_regs) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (cd.lane + (int64_t)r * T < cd.n) {
+                double w = cd.w[r], iw = 1.0 - w;
+                pt *= fma(aopt, w, iw);
+                pi *= iw;
+                if ((r & 7) == 7) renorm();
+            }
+    } else {
+        int k = 0;
+        for (int64_t i = cd.lane; i < cd.n; i += T) {
+            double w = cd.ld(i), iw = 1.0 - w;
+            pt *= fma(aopt, w, iw);
+            pi *= iw;
+            if ((++k & 7) == 0) renorm();
+        }
+    }
+    renorm();
+    pt = team_prod<T>(pt);   // each factor in [0.5, 1): at worst 2^-64
+    pi = team_prod<T>(pi);
+    et = team_sum_i32<T>(et);
+    ei = team_sum_i32<T>(ei);
+    const double LN2 = 0.6931471805599453;
+    double dl = log(pt * rcp_fast(pi)) + (double)(et - ei) * LN2;   // logL sums: log prod t - log prod (1-w)
+    return 2 * (dl - S * aopt);
 }
 
 template <int T>
@@ -278,31 +364,82 @@ __device__ __forceinline__ bool cell_setup(const CellArgs &p, int64_t &cell, int
     return true;
 }
 
+// One team per cell.  Cells whose first pass of the schedule asks for a
+// restart (about one in seven of sparse cells) are not iterated in place,
+// where they would hold up the other teams of their wavefront: the team posts
+// (cell, new start) to a queue in LDS and the workgroup then serves the queue
+// with densely packed teams that reload the cell's weights (L2-resident).
 template <int T, int R>
 __global__ __launch_bounds__(256) void cell_fit_kernel(CellArgs p, const double *guess, double guess0,
                                                        const double *beta, double beta0,
                                                        double *alpha, double *ts, int32_t *flags)
 {
-    int64_t cell, lo, n;
-    int lane;
-    double S, B;
-    bool bad;
-    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
-    CellData<T, R> cd;
-    cd.load(p.we + lo, n, lane, p.swap != 0);
-    int fl = 0;
-    double a, t = 0.0;
-    if (bad) {
-        fl = GODOT_F_FAILED;
-        a = t = qnan();
-    } else {
-        a = fit_alpha(cd, S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
-        if (ts) t = test_statistic(cd, S, a);
+    constexpr int NTEAM = 256 / T;
+    __shared__ int q_count[2];
+    __shared__ int q_cell[2][NTEAM];
+    __shared__ double q_g[2][NTEAM], q_b[2][NTEAM];
+    const int lane = threadIdx.x & (T - 1);
+    const int team = threadIdx.x / T;
+    const int64_t cell0 = (int64_t)blockIdx.x * NTEAM;
+    if (threadIdx.x < 2) q_count[threadIdx.x] = 0;
+    __syncthreads();
+
+    auto finish = [&](int64_t cell, const CellData<T, R> &cd, double S, double a, int fl) {
+        double t = 0.0;
+        if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, S, a);
+        if (lane == 0) {
+            alpha[cell] = a;
+            if (ts) ts[cell] = (fl & GODOT_F_FAILED) ? qnan() : t;
+            if (flags) flags[cell] = fl;
+        }
+    };
+    auto load_cell = [&](int64_t cell, CellData<T, R> &cd, double &S, bool &bad) {
+        int64_t lo = p.lo[cell], hi = p.hi[cell];
+        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        S = p.swap ? p.B[cell] : p.S[cell];
+        cd.load(p.we + (bad ? 0 : lo), bad ? 0 : hi - lo, lane, p.swap != 0);
+    };
+    // depth-th pass of cell; posts a restart to queue `qw` or writes the result
+    auto serve = [&](int64_t cell, double g, double b, int depth, int qw) {
+        CellData<T, R> cd;
+        double S;
+        bool bad;
+        load_cell(cell, cd, S, bad);
+        if (bad) {
+            finish(cell, cd, S, qnan(), GODOT_F_FAILED);
+            return;
+        }
+        int fl = depth << 1;
+        double a;
+        bool at_zero;
+        if (fit_attempt(cd, S, g, b, a, at_zero)) {
+            if (at_zero) finish(cell, cd, S, 0.0, fl | GODOT_F_AT_ZERO);
+            else finish(cell, cd, S, a + 1, fl);
+        } else if (depth > 2) {
+            double an = max_numerical(cd, S, fl);
+            finish(cell, cd, S, an, fl);
+        } else if (lane == 0) {
+            int slot = atomicAdd(&q_count[qw], 1);
+            q_cell[qw][slot] = (int)(cell - cell0);
+            q_g[qw][slot] = (a + 1) - 1;
+            q_b[qw][slot] = (b + 1) - 1;
+        }
+    };
+
+    {
+        const int64_t cell = cell0 + team;
+        if (cell < p.ncell)
+            serve(cell, (guess ? guess[cell] : guess0) - 1, (beta ? beta[cell] : beta0) - 1, 0, 0);
     }
-    if (lane == 0) {
-        alpha[cell] = a;
-        if (ts) ts[cell] = t;
-        if (flags) flags[cell] = fl;
+    // restart rounds: depth 1, 2, 3 (the reference recurses at most that deep)
+    for (int depth = 1; depth <= 3; ++depth) {
+        const int qr = (depth - 1) & 1, qw = depth & 1;
+        __syncthreads();
+        const int n = q_count[qr];
+        if (n == 0) break;
+        if (threadIdx.x == 0) q_count[qw] = 0;
+        __syncthreads();
+        if (team < n) serve(cell0 + q_cell[qr][team], q_g[qr][team], q_b[qr][team], depth, qw);
     }
 }
 
@@ -835,8 +972,9 @@ namespace {
 inline int pick_team(int64_t nph, int64_t ncell)
 {
     double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
-    if (mean <= 8) return 4;
-    if (mean <= 40) return 16;
+    if (mean <= 6) return 4;
+    if (mean <= 48) return 8;
+    if (mean <= 200) return 32;
     return 64;
 }
 
@@ -856,15 +994,19 @@ inline int check_cells(const void *we, int64_t nph, const void *lo, const void *
         switch (T_) {                                                                       \
         case 4: {                                                                           \
             dim3 grid((unsigned)ceil_div(ncell, 256 / 4));                                  \
-            hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(256), 0, st, __VA_ARGS__);        \
+            hipLaunchKernelGGL((KERNEL<4, 8>), grid, dim3(256), 0, st, __VA_ARGS__);        \
         } break;                                                                            \
-        case 16: {                                                                          \
-            dim3 grid((unsigned)ceil_div(ncell, 256 / 16));                                 \
-            hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+        case 8: {                                                                           \
+            dim3 grid((unsigned)ceil_div(ncell, 256 / 8));                                  \
+            hipLaunchKernelGGL((KERNEL<8, 8>), grid, dim3(256), 0, st, __VA_ARGS__);        \
+        } break;                                                                            \
+        case 32: {                                                                          \
+            dim3 grid((unsigned)ceil_div(ncell, 256 / 32));                                 \
+            hipLaunchKernelGGL((KERNEL<32, 8>), grid, dim3(256), 0, st, __VA_ARGS__);       \
         } break;                                                                            \
         default: {                                                                          \
             dim3 grid((unsigned)ceil_div(ncell, 256 / 64));                                 \
-            hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+            hipLaunchKernelGGL((KERNEL<64, 16>), grid, dim3(256), 0, st, __VA_ARGS__);      \
         } break;                                                                            \
         }                                                                                   \
     } while (0)

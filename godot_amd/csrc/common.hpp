@@ -32,26 +32,59 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- device side -----------------------------------------------------------
 constexpr int WAVE = 64;
 
-// Butterfly reductions inside aligned groups of T lanes (T a power of two
-// <= 64).  Every lane of the group ends with the bit-identical result, so
-// data-dependent branches taken on it are uniform across the group.
-template <int T>
-__device__ __forceinline__ double team_sum(double v)
+// Cross-lane moves by DPP (data-parallel primitives: no LDS round trip).
+//   0xB1  quad_perm [1,0,3,2]   lane ^ 1
+//   0x4E  quad_perm [2,3,0,1]   lane ^ 2
+//   0x141 row_half_mirror       lane -> 7 - lane inside each group of 8
+//   0x140 row_mirror            lane -> 15 - lane inside each row of 16
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-#pragma unroll
-    for (int o = T / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
 }
 
-template <int T>
-__device__ __forceinline__ double team_max(double v)
-{
-#pragma unroll
-    for (int o = T / 2; o > 0; o >>= 1) {
-        double u = __shfl_xor(v, o, WAVE);
-        v = (u > v) ? u : v;
+// Reductions inside aligned groups of T lanes (T a power of two <= 64).
+// Each step pairs two disjoint sub-groups whose lanes already agree, and
+// + / max / * are commutative, so every lane of the group ends with the
+// bit-identical result: branches taken on it are uniform across the group.
+#define GODOT_TEAM_REDUCE(NAME, TYPE, MOVE, SHFL, OP)                    \
+    template <int T>                                                     \
+    __device__ __forceinline__ TYPE NAME(TYPE v)                         \
+    {                                                                    \
+        if (T >= 2) { TYPE u = MOVE<0xB1>(v); v = OP(v, u); }            \
+        if (T >= 4) { TYPE u = MOVE<0x4E>(v); v = OP(v, u); }            \
+        if (T >= 8) { TYPE u = MOVE<0x141>(v); v = OP(v, u); }           \
+        if (T >= 16) { TYPE u = MOVE<0x140>(v); v = OP(v, u); }          \
+        if (T >= 32) { TYPE u = SHFL(v, 16, WAVE); v = OP(v, u); }       \
+        if (T >= 64) { TYPE u = SHFL(v, 32, WAVE); v = OP(v, u); }       \
+        return v;                                                        \
     }
-    return v;
+#define GODOT_OP_ADD(a, b) ((a) + (b))
+#define GODOT_OP_MUL(a, b) ((a) * (b))
+#define GODOT_OP_MAX(a, b) (((b) > (a)) ? (b) : (a))
+GODOT_TEAM_REDUCE(team_sum, double, dpp_f64, __shfl_xor, GODOT_OP_ADD)
+GODOT_TEAM_REDUCE(team_prod, double, dpp_f64, __shfl_xor, GODOT_OP_MUL)
+GODOT_TEAM_REDUCE(team_max, double, dpp_f64, __shfl_xor, GODOT_OP_MAX)
+GODOT_TEAM_REDUCE(team_sum_i32, int, dpp_i32, __shfl_xor, GODOT_OP_ADD)
+
+// 1/d for finite d away from 0 and from the ends of the exponent range:
+// hardware estimate + two Newton steps (about 1 ulp).  No scaling, no
+// special-case fix-up: callers guarantee the range.
+__device__ __forceinline__ double rcp_fast(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    return fma(x, e, x);
 }
 
 // Python's max(a, b): b only if b > a (so a NaN second argument yields a).
