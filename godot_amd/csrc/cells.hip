@@ -74,6 +74,46 @@ struct CellData {
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
     }
 
+    // sum over the cell of log(t_i) and of g_i, where f(w, t, g) yields the
+    // positive t_i and the addend g_i of one photon.  The logarithms are taken
+    // of the running product (mantissa renormalised into [0.5, 1) every eight
+    // factors, exponent kept as an integer): one log per cell, not per photon.
+    template <class F>
+    __device__ __forceinline__ void logsum(F f, double &logs, double &gsum) const
+    {
+        double pr = 1.0, gs = 0.0;
+        int ex = 0;
+        auto renorm = [&]() {
+            ex += __builtin_amdgcn_frexp_exp(pr);
+            pr = __builtin_amdgcn_frexp_mant(pr);
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + (int64_t)r * T < n) {
+                    double t, g;
+                    f(w[r], t, g);
+                    pr *= t;
+                    gs += g;
+                    if ((r & 7) == 7) renorm();
+                }
+        } else {
+            int k = 0;
+            for (int64_t i = lane; i < n; i += T) {
+                double t, g;
+                f(ld(i), t, g);
+                pr *= t;
+                gs += g;
+                if ((++k & 7) == 0) renorm();
+            }
+        }
+        renorm();
+        pr = team_prod<T>(pr);   // factors in [0.5, 1): at worst 2^-64
+        ex = team_sum_i32<T>(ex);
+        gsum = team_sum<T>(gs);
+        logs = log(pr) + (double)ex * 0.6931471805599453;
+    }
+
     template <class F>
     __device__ __forceinline__ double maxof(F f) const
     {
@@ -292,11 +332,12 @@ __device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, do
 template <int T, int R>
 __device__ double loglike(const CellData<T, R> &cd, double S, double alpha)
 {
-    double acc[1];
-    cd.template sums<1>([=](double w, double (&s)[1]) {
-        s[0] += log(w * alpha + (1.0 - w));
-    }, acc);
-    return acc[0] - S * alpha;
+    double ls, unused;
+    cd.logsum([=](double w, double &t, double &g) {
+        t = fma(w, alpha, 1.0 - w);
+        g = 0.0;
+    }, ls, unused);
+    return ls - S * alpha;
 }
 
 // 2 (logL(aopt) - logL(0))   (core.py:982-994).
@@ -572,11 +613,12 @@ __global__ __launch_bounds__(256) void cell_beta_kernel(CellArgs p, const double
         bt = fit_beta(cd, B, al, guess ? guess[cell] : guess0, fl);
         if (lprof) {
             double b = bt - 1, a = al - 1;
-            double acc[1];
-            cd.template sums<1>([=](double w, double (&s)[1]) {
-                s[0] += log((1.0 + b) + w * (a - b));
-            }, acc);
-            lp = acc[0] - S * (1 + a) - B * (1 + b);
+            double ls, unused;
+            cd.logsum([=](double w, double &t, double &g) {
+                t = fma(w, a - b, 1.0 + b);
+                g = 0.0;
+            }, ls, unused);
+            lp = ls - S * (1 + a) - B * (1 + b);
         }
     }
     if (lane == 0) {
@@ -611,18 +653,16 @@ __device__ Support support_search(const CellData<T, R> &cd, double S, double aop
     double acc[2];
     // Newton step on logL(a) - llmax + dlogl = 0
     auto f0f1 = [&](double a) {
-        cd.template sums<2>([=](double w, double (&s)[2]) {
-            double t = a * w + (1.0 - w);
-            s[0] += log(t);
-            s[1] += w / t;
-        }, acc);
+        cd.logsum([=](double w, double &t, double &g) {
+            t = fma(a, w, 1.0 - w);
+            g = w * rcp_fast(t);
+        }, acc[0], acc[1]);
     };
     if (aopt == 0) {   // core.py:869-880
-        cd.template sums<2>([](double w, double (&s)[2]) {
-            double iw = 1.0 - w;
-            s[0] += log(iw);
-            s[1] += w / iw;
-        }, acc);
+        cd.logsum([](double w, double &t, double &g) {
+            t = 1.0 - w;
+            g = w * rcp_fast(t);
+        }, acc[0], acc[1]);
         llmax = acc[0];
         amax = pymax(0.0, -(llmax + dlogl) / (acc[1] - S));
         for (int i = 0; i < 10; ++i) {
@@ -633,12 +673,11 @@ __device__ Support support_search(const CellData<T, R> &cd, double S, double aop
             if (fabs(f0) < 0.1) break;
         }
     } else {           // core.py:881-895
-        cd.template sums<2>([=](double w, double (&s)[2]) {
-            double t = aopt * w + (1.0 - w);
-            s[0] += log(t);
-            double q = w / t;
-            s[1] += q * q;
-        }, acc);
+        cd.logsum([=](double w, double &t, double &g) {
+            t = fma(aopt, w, 1.0 - w);
+            double q = w * rcp_fast(t);
+            g = q * q;
+        }, acc[0], acc[1]);
         llmax = acc[0] - S * aopt;
         double f2 = fabs(acc[1]);
         amax = aopt + sqrt(2 * dlogl / f2);
@@ -754,22 +793,32 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
             double a = grid_point(s_amin[c], s_amax[c], s_step[c], i, npt);
             const double *w = p.we + s_lo[c];
             int64_t n = s_n[c];
-            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+            // log of the product of the terms (see CellData::logsum): two
+            // independent product chains, renormalised every eight factors
+            double p0 = 1.0, p1 = 1.0;
+            int ex = 0;
             int64_t j = 0;
-            for (; j + 4 <= n; j += 4) {
-                double w0 = w[j], w1 = w[j + 1], w2 = w[j + 2], w3 = w[j + 3];
-                if (swap) { w0 = 1.0 - w0; w1 = 1.0 - w1; w2 = 1.0 - w2; w3 = 1.0 - w3; }
-                acc0 += log(w0 * a + (1.0 - w0));
-                acc1 += log(w1 * a + (1.0 - w1));
-                acc2 += log(w2 * a + (1.0 - w2));
-                acc3 += log(w3 * a + (1.0 - w3));
+            for (; j + 8 <= n; j += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    double w0 = w[j + q], w1 = w[j + q + 1];
+                    if (swap) { w0 = 1.0 - w0; w1 = 1.0 - w1; }
+                    p0 *= fma(w0, a, 1.0 - w0);
+                    p1 *= fma(w1, a, 1.0 - w1);
+                }
+                ex += __builtin_amdgcn_frexp_exp(p0) + __builtin_amdgcn_frexp_exp(p1);
+                p0 = __builtin_amdgcn_frexp_mant(p0);
+                p1 = __builtin_amdgcn_frexp_mant(p1);
             }
             for (; j < n; ++j) {
                 double w0 = w[j];
                 if (swap) w0 = 1.0 - w0;
-                acc0 += log(w0 * a + (1.0 - w0));
+                p0 *= fma(w0, a, 1.0 - w0);
             }
-            s_cod[k] = ((acc0 + acc1) + (acc2 + acc3)) - s_S[c] * a;
+            p0 *= p1;
+            ex += __builtin_amdgcn_frexp_exp(p0);
+            p0 = __builtin_amdgcn_frexp_mant(p0);
+            s_cod[k] = (log(p0) + (double)ex * 0.6931471805599453) - s_S[c] * a;
         }
         __syncthreads();
         // phase 3: agreement of the grid maximum with llmax (core.py:923-929)
