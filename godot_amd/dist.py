@@ -1,0 +1,126 @@
+"""Sharding of the hot path over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for tests).
+
+The path shards without any data-path exchange:
+  * cell fits / profile grids: contiguous cell ranges balanced by photon
+    count; every rank reads only its slice of the photon array;
+  * Z^2_m searches: contiguous ranges of trial-frequency indices; the photon
+    list is replicated (16 MB for 1e6 photons);
+  * multi-source batches: sources dealt round-robin.
+The only collectives are result collection: an all-gather of fixed-width
+per-cell records (padded to the largest shard) and, for searches, an
+all-reduce(max) / all-gather of per-rank maxima.  Both are latency-bound
+(KBs to a few MB), one hop on the xGMI mesh.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def split_by_weight(cum, nparts):
+    """Boundaries b[0..nparts] of contiguous ranges of items with about equal
+    total weight; cum[i] = total weight of items [0, i) (len n+1, cum[0] = 0)."""
+    cum = np.asarray(cum)
+    n = len(cum) - 1
+    targets = cum[-1] * (np.arange(1, nparts) / float(nparts))
+    cuts = np.searchsorted(cum, targets, side='left')
+    b = np.concatenate([[0], np.clip(cuts, 0, n), [n]]).astype(np.int64)
+    return np.maximum.accumulate(b)
+
+
+def cell_shard(counts, rank=None, world=None, group=None):
+    """(first_cell, last_cell_exclusive) of this rank: contiguous cells,
+    balanced by photon count (+1 per cell so that empty cells also spread)."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    c = np.asarray(counts, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(c + 1)])
+    b = split_by_weight(cum, world)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def frequency_shard(nf, rank=None, world=None, group=None):
+    """(first_index, count) of this rank's contiguous slice of nf trial frequencies."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    per = -(-nf // world)
+    j0 = min(rank * per, nf)
+    return j0, min(per, nf - j0)
+
+
+def source_shard(nsource, rank=None, world=None, group=None):
+    """Indices of the sources this rank owns (round-robin)."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return list(range(rank, nsource, world))
+
+
+def all_gather_ragged(local, sizes=None, group=None):
+    """Concatenate per-rank tensors with different first dimensions, in rank
+    order, on every rank.  One all-gather of the sizes, one of the padded
+    records."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    if sizes is None:
+        allsz = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(allsz, n, group=group)
+        sizes = [int(x) for x in allsz.cpu()]
+    nmax = max(sizes)
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    out = out.view((world, nmax) + tuple(local.shape[1:]))
+    return torch.cat([out[r, :sizes[r]] for r in range(world)], dim=0)
+
+
+def fit_cells_sharded(counts, fit_fn, group=None):
+    """Fit this rank's cells and return the records of ALL cells on every rank.
+
+    counts : host array of photons per cell (same on every rank)
+    fit_fn : callable(first_cell, last_cell) -> (n_local, k) tensor of per-cell
+             records (e.g. alpha, TS, flags) computed on this rank's device
+    """
+    c0, c1 = cell_shard(counts, group=group)
+    rec = fit_fn(c0, c1)
+    if rec.shape[0] != c1 - c0:
+        raise ValueError('fit_fn returned %d records for %d cells' % (rec.shape[0], c1 - c0))
+    rank, world = _world(group)
+    sizes = [cell_shard(counts, r, world)[1] - cell_shard(counts, r, world)[0] for r in range(world)]
+    return all_gather_ragged(rec, sizes=sizes, group=group)
+
+
+def search_sharded(nf, search_fn, gather_spectrum=False, group=None):
+    """Run search_fn(j0, n) -> (n,) statistic tensor on this rank's slice of nf
+    trial frequencies.  Returns (global_max, global_argmax) and, if
+    gather_spectrum, the full spectrum on every rank."""
+    rank, world = _world(group)
+    j0, n = frequency_shard(nf, group=group)
+    z = search_fn(j0, n)
+    if n > 0:
+        zmax, imax = torch.max(z, dim=0)
+        best = torch.stack([zmax.to(torch.float64), (imax + j0).to(torch.float64)])
+    else:
+        best = torch.tensor([-np.inf, -1.0], dtype=torch.float64, device=z.device)
+    if world > 1:
+        allbest = torch.empty((world, 2), dtype=torch.float64, device=best.device)
+        dist.all_gather_into_tensor(allbest, best.unsqueeze(0).contiguous(), group=group)
+        k = int(torch.argmax(allbest[:, 0]).cpu())
+        best = allbest[k]
+    spec = None
+    if gather_spectrum:
+        sizes = [frequency_shard(nf, r, world)[1] for r in range(world)]
+        spec = all_gather_ragged(z, sizes=sizes, group=group)
+    return float(best[0].cpu()), int(best[1].cpu()), spec

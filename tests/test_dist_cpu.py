@@ -1,0 +1,107 @@
+"""world_size-2 gloo tests (CPU) of the sharding / result-collection layer.
+The per-rank compute is a numpy stand-in (the oracle): the GPU kernels are
+covered by the -m gpu tests, this covers the multi-process path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from godot_amd import dist as gd
+        from oracle import godot_oracle as orc
+        rng = np.random.default_rng(5)
+        ncell = 37
+        counts = rng.integers(0, 40, ncell)
+        counts[5] = 0
+        off = np.concatenate([[0], np.cumsum(counts)])
+        we = np.clip(rng.beta(0.3, 1.5, off[-1]), 1e-6, 1 - 1e-6)
+        S = np.maximum(counts * 0.17, 0.05)
+
+        def fit_fn(c0, c1):
+            out = np.empty((c1 - c0, 2))
+            with np.errstate(all='ignore'):
+                for i, c in enumerate(range(c0, c1)):
+                    cl = orc.CellLike(we[off[c]:off[c + 1]], S[c], 0.2)
+                    a = cl.get_max()
+                    out[i] = a, cl.get_ts(a)
+            return torch.from_numpy(out)
+
+        rec = gd.fit_cells_sharded(counts, fit_fn)
+        ref = fit_fn(0, ncell)
+        ok1 = bool(torch.equal(rec, ref))
+        c0, c1 = gd.cell_shard(counts)
+
+        t = np.sort(rng.uniform(0, 1e6, 400))
+        w = rng.uniform(0.1, 0.9, 400)
+        nf = 101
+
+        def search_fn(j0, n):
+            return torch.from_numpy(orc.z2m(t, w, 1e-3, 2e-7, n, m=2, j0=j0))
+
+        zmax, jmax, spec = gd.search_sharded(nf, search_fn, gather_spectrum=True)
+        full = orc.z2m(t, w, 1e-3, 2e-7, nf, m=2)
+        ok2 = (jmax == int(np.argmax(full))) and (zmax == full.max()) and \
+            np.array_equal(spec.numpy(), full)
+        q.put((rank, ok1, ok2, (c0, c1), gd.source_shard(7)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_fit_and_search():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(r[1] and r[2] for r in res)
+    (a0, a1), (b0, b1) = res[0][3], res[1][3]
+    assert a0 == 0 and a1 == b0 and b1 == 37 and 0 < a1 < 37
+    assert res[0][4] == [0, 2, 4, 6] and res[1][4] == [1, 3, 5]
+
+
+def test_shard_helpers_single_process():
+    sys.path.insert(0, REPO)
+    from godot_amd import dist as gd
+    counts = np.array([100, 0, 0, 1, 1, 1, 50, 50, 0, 3])
+    cover = []
+    for r in range(4):
+        c0, c1 = gd.cell_shard(counts, r, 4)
+        cover += list(range(c0, c1))
+    assert cover == list(range(len(counts)))
+    tot = 0
+    for r in range(3):
+        j0, n = gd.frequency_shard(10, r, 3)
+        assert j0 == tot
+        tot += n
+    assert tot == 10
+    assert gd.frequency_shard(2, 3, 4) == (2, 0)
+    b = gd.split_by_weight(np.array([0, 10, 20, 30, 40]), 2)
+    assert list(b) == [0, 2, 4]
