@@ -114,6 +114,45 @@ struct CellData {
         logs = log(pr) + (double)ex * 0.6931471805599453;
     }
 
+    // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
+    // ratio of the two renormalised products
+    template <class F>
+    __device__ __forceinline__ double logratio(F f) const
+    {
+        double p1 = 1.0, p2 = 1.0;
+        int ex = 0;
+        auto renorm = [&]() {
+            ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
+            p1 = __builtin_amdgcn_frexp_mant(p1);
+            p2 = __builtin_amdgcn_frexp_mant(p2);
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + (int64_t)r * T < n) {
+                    double t1, t2;
+                    f(w[r], t1, t2);
+                    p1 *= t1;
+                    p2 *= t2;
+                    if ((r & 7) == 7) renorm();
+                }
+        } else {
+            int k = 0;
+            for (int64_t i = lane; i < n; i += T) {
+                double t1, t2;
+                f(ld(i), t1, t2);
+                p1 *= t1;
+                p2 *= t2;
+                if ((++k & 7) == 0) renorm();
+            }
+        }
+        renorm();
+        p1 = team_prod<T>(p1);
+        p2 = team_prod<T>(p2);
+        ex = team_sum_i32<T>(ex);
+        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
+    }
+
     template <class F>
     __device__ __forceinline__ double maxof(F f) const
     {
@@ -129,14 +168,104 @@ struct CellData {
     }
 };
 
+// Weights of one cell owned by ONE lane: the first R weights live in
+// registers, zero-padded.  A zero weight adds nothing to any sum of the fit
+// (w/(t2 + a w) = 0) and multiplies the likelihood products by exactly 1, so
+// the register part needs no predication.  Photons beyond R (rare) are read
+// from memory in every pass.  Same interface as CellData; no cross-lane
+// traffic.
+template <int R>
+struct LaneCell {
+    double w[R];
+    const double *g;   // the cell's weights in global memory (for the tail)
+    int n;
+    bool swap;
+
+    __device__ __forceinline__ double tail(int j) const
+    {
+        double v = g[j];
+        return swap ? 1.0 - v : v;
+    }
+
+    template <int NS, class F>
+    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) f(w[r], acc);
+        for (int j = R; j < n; ++j) f(tail(j), acc);
+    }
+
+    template <class F>
+    __device__ __forceinline__ void logsum(F f, double &logs, double &gsum) const
+    {
+        double pr = 1.0, gs = 0.0;
+        int ex = 0;
+        auto step = [&](double wv, int j) {
+            double t, g;
+            f(wv, t, g);
+            pr *= t;
+            gs += g;
+            if ((j & 7) == 7) {
+                ex += __builtin_amdgcn_frexp_exp(pr);
+                pr = __builtin_amdgcn_frexp_mant(pr);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r) step(w[r], r);
+        for (int j = R; j < n; ++j) step(tail(j), j);
+        ex += __builtin_amdgcn_frexp_exp(pr);
+        pr = __builtin_amdgcn_frexp_mant(pr);
+        gsum = gs;
+        logs = log(pr) + (double)ex * 0.6931471805599453;
+    }
+
+    template <class F>
+    __device__ __forceinline__ double logratio(F f) const
+    {
+        double p1 = 1.0, p2 = 1.0;
+        int ex = 0;
+        auto step = [&](double wv, int j) {
+            double t1, t2;
+            f(wv, t1, t2);
+            p1 *= t1;
+            p2 *= t2;
+            if ((j & 7) == 7) {
+                ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
+                p1 = __builtin_amdgcn_frexp_mant(p1);
+                p2 = __builtin_amdgcn_frexp_mant(p2);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r) step(w[r], r);
+        for (int j = R; j < n; ++j) step(tail(j), j);
+        ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
+        p1 = __builtin_amdgcn_frexp_mant(p1);
+        p2 = __builtin_amdgcn_frexp_mant(p2);
+        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
+    }
+
+    template <class F>
+    __device__ __forceinline__ double maxof(F f) const
+    {
+        double m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < n) m = fmax(m, f(w[r]));
+        for (int j = R; j < n; ++j) m = fmax(m, f(tail(j)));
+        return m;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // get_max with the background level fixed: reference core.py:632-691.
 // g = guess - 1, b = beta - 1 (the reference's zero-based parameters).
 // ---------------------------------------------------------------------------
 
 // f(a) = sum w/(t2 + a w) - S with t2 = 1 + b (1 - w)
-template <int T, int R>
-__device__ double score(const CellData<T, R> &cd, double a, double b, double S)
+template <class CD>
+__device__ double score(const CD &cd, double a, double b, double S)
 {
     double acc[1];
     cd.template sums<1>([=](double w, double (&s)[1]) {
@@ -148,8 +277,8 @@ __device__ double score(const CellData<T, R> &cd, double a, double b, double S)
 
 // scipy.optimize.brentq (Zeros/brentq.c) on the score function with beta = 1,
 // as the reference's get_max_numerical uses it (core.py:728-739).
-template <int T, int R>
-__device__ double max_numerical(const CellData<T, R> &cd, double S, int &flags)
+template <class CD>
+__device__ __noinline__ double max_numerical(const CD &cd, double S, int &flags)
 {
     flags |= GODOT_F_BRENT;
     if (score(cd, -1.0, 0.0, S) < 0) {
@@ -215,27 +344,25 @@ __device__ double max_numerical(const CellData<T, R> &cd, double S, int &flags)
     return qnan();
 }
 
-template <int T, int R, bool B0>
-__device__ bool fit_attempt_impl(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
-                                 bool &at_zero);
+template <class CD, bool B0>
+__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero);
 
 // One pass of the fixed schedule (core.py:639-680) from the zero-based start
 // values g = guess - 1, b = beta - 1.  Returns true when the result `a` (zero-
 // based) is final, false when the reference would call itself again with
 // guess = a + 1 (core.py:684-689).
-template <int T, int R>
-__device__ bool fit_attempt(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
+template <class CD>
+__device__ bool fit_attempt(const CD &cd, double S, double g, double b, double &a_out,
                             bool &at_zero)
 {
     // background level fixed at its nominal value (beta = 1): t2 = 1 exactly
-    if (b == 0.0) return fit_attempt_impl<T, R, true>(cd, S, g, 0.0, a_out, at_zero);
-    return fit_attempt_impl<T, R, false>(cd, S, g, b, a_out, at_zero);
+    if (b == 0.0) return fit_attempt_impl<CD, true>(cd, S, g, 0.0, a_out, at_zero);
+    return fit_attempt_impl<CD, false>(cd, S, g, b, a_out, at_zero);
 }
 
 
-template <int T, int R, bool B0>
-__device__ bool fit_attempt_impl(const CellData<T, R> &cd, double S, double g, double b, double &a_out,
-                                 bool &at_zero)
+template <class CD, bool B0>
+__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero)
 {
     double acc[3];
     at_zero = false;
@@ -306,8 +433,8 @@ __device__ bool fit_attempt_impl(const CellData<T, R> &cd, double S, double g, d
 
 // get_max in place: used where a cell's weights are already loaded and no
 // other team can take over its restarts (the profile-grid kernel).
-template <int T, int R>
-__device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, double beta, int &flags)
+template <class CD>
+__device__ double fit_alpha(const CD &cd, double S, double guess, double beta, int &flags)
 {
     double g = guess - 1;
     double b = beta - 1;
@@ -329,8 +456,8 @@ __device__ double fit_alpha(const CellData<T, R> &cd, double S, double guess, do
 }
 
 // logL(alpha) = sum log(alpha w + (1 - w)) - S alpha   (core.py:353-364)
-template <int T, int R>
-__device__ double loglike(const CellData<T, R> &cd, double S, double alpha)
+template <class CD>
+__device__ double loglike(const CD &cd, double S, double alpha)
 {
     double ls, unused;
     cd.logsum([=](double w, double &t, double &g) {
@@ -340,49 +467,16 @@ __device__ double loglike(const CellData<T, R> &cd, double S, double alpha)
     return ls - S * alpha;
 }
 
-// 2 (logL(aopt) - logL(0))   (core.py:982-994).
-// sum_i log(t_i) is formed as the log of the product of the t_i: the running
-// product is renormalised (mantissa in [0.5, 1), exponent kept as an integer)
-// often enough that it can neither overflow nor underflow, and one logarithm
-// per cell replaces one per photon.  The difference from summing individually
-// rounded logarithms is a few ulp of the terms.
-template <int T, int R>
-__device__ double test_statistic(const CellData<T, R> &cd, double S, double aopt)
+// 2 (logL(aopt) - logL(0))   (core.py:982-994): the two sums of logarithms
+// are taken together as one log of a ratio of renormalised products.
+template <class CD>
+__device__ double test_statistic(const CD &cd, double S, double aopt)
 {
     if (S == 0 || aopt == 0) return 0.0;
-    double pt = 1.0, pi = 1.0;   // products of (aopt w + 1 - w) and of (1 - w)
-    int et = 0, ei = 0;
-    auto renorm = [&]() {
-        et += __builtin_amdgcn_frexp_exp(pt);
-        pt = __builtin_amdgcn_frexp_mant(pt);
-        ei += __builtin_amdgcn_frexp_exp(pi);
-        pi = __builtin_amdgcn_frexp_mant(pi);
-    };
-    if (cd.in_regs) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (cd.lane + (int64_t)r * T < cd.n) {
-                double w = cd.w[r], iw = 1.0 - w;
-                pt *= fma(aopt, w, iw);
-                pi *= iw;
-                if ((r & 7) == 7) renorm();
-            }
-    } else {
-        int k = 0;
-        for (int64_t i = cd.lane; i < cd.n; i += T) {
-            double w = cd.ld(i), iw = 1.0 - w;
-            pt *= fma(aopt, w, iw);
-            pi *= iw;
-            if ((++k & 7) == 0) renorm();
-        }
-    }
-    renorm();
-    pt = team_prod<T>(pt);   // each factor in [0.5, 1): at worst 2^-64
-    pi = team_prod<T>(pi);
-    et = team_sum_i32<T>(et);
-    ei = team_sum_i32<T>(ei);
-    const double LN2 = 0.6931471805599453;
-    double dl = log(pt * rcp_fast(pi)) + (double)(et - ei) * LN2;   // logL sums: log prod t - log prod (1-w)
+    double dl = cd.logratio([=](double w, double &t1, double &t2) {
+        t2 = 1.0 - w;
+        t1 = fma(aopt, w, t2);
+    });
     return 2 * (dl - S * aopt);
 }
 
@@ -484,6 +578,176 @@ __global__ __launch_bounds__(256) void cell_fit_kernel(CellArgs p, const double 
     }
 }
 
+// Sparse cells (a few to a few tens of photons): one LANE per cell, one
+// wavefront (64 cells) per workgroup.  The wavefront reads the photons of its
+// cells with coalesced loads through a small LDS bounce buffer (when the cells
+// are contiguous in memory, which binning produces) and every lane keeps its
+// cell's weights in registers for the whole schedule: no cross-lane
+// reductions, and the per-cell scalar work (Newton updates, clamps, the one
+// logarithm) is shared by 64 cells per instruction.  Cells that ask for a
+// restart, and cells too large for a lane, go through a queue in LDS and are
+// served by 16-lane teams (they read the weights again; L2 holds them).
+// Small LDS and a 128-register cap keep four wavefronts per SIMD resident so
+// that the load latency of one hides behind the arithmetic of the others.
+constexpr int WK_BOUNCE = 512;   // photons per bounce chunk (4 KB)
+
+template <int RL>
+__global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const double *guess, double guess0,
+                                                              const double *beta, double beta0,
+                                                              double *alpha, double *ts, int32_t *flags)
+{
+    __shared__ double s_b[WK_BOUNCE];
+    __shared__ int q_count[2];
+    __shared__ short q_cell[2][64], q_depth[2][64];
+    __shared__ double q_g[2][64], q_b[2][64];
+
+    const int lane = threadIdx.x;
+    const int64_t cell0 = (int64_t)blockIdx.x * 64;
+    const int64_t cell = cell0 + lane;
+    const bool have = cell < p.ncell;
+    const bool swap = p.swap != 0;
+    if (lane < 2) q_count[lane] = 0;
+
+    int64_t lo = 0, hi = 0;
+    bool bad = false;
+    double S = 0.0;
+    if (have) {
+        lo = p.lo[cell];
+        hi = p.hi[cell];
+        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        S = swap ? p.B[cell] : p.S[cell];
+    }
+    const int64_t n64 = (have && !bad) ? hi - lo : 0;
+    const bool big = n64 > 4 * RL;              // served by a team, not by this lane
+    const int n = big ? 0 : (int)n64;
+
+    LaneCell<RL> lc;
+    lc.g = p.we + (bad ? 0 : lo);
+    lc.n = n;
+    lc.swap = swap;
+#pragma unroll
+    for (int r = 0; r < RL; ++r) lc.w[r] = 0.0;
+
+    // are the wavefront's cells one contiguous run of photons?
+    const int64_t next_lo = __shfl_down((long long)lo, 1, WAVE);
+    bool link_ok = !bad;
+    if (have && !bad && lane < 63 && cell + 1 < p.ncell) link_ok = (next_lo == hi);
+    const bool contiguous = __all(link_ok ? 1 : 0);
+    if (contiguous) {
+        const int64_t base = __shfl((long long)lo, 0, WAVE);
+        const int nlast = (int)((p.ncell - cell0) < 64 ? (p.ncell - cell0) : 64) - 1;
+        const int64_t end = __shfl((long long)hi, nlast, WAVE);
+        const int64_t off = lo - base;          // this cell's first photon in the run
+        for (int64_t c0 = 0; c0 < end - base; c0 += WK_BOUNCE) {
+            const int m = (int)((end - base - c0) < WK_BOUNCE ? (end - base - c0) : WK_BOUNCE);
+            double v[WK_BOUNCE / 64];
+#pragma unroll
+            for (int u = 0; u < WK_BOUNCE / 64; ++u) {
+                int k = u * 64 + lane;
+                v[u] = (k < m) ? p.we[base + c0 + k] : 0.0;
+            }
+            __syncthreads();                    // the previous chunk has been read
+#pragma unroll
+            for (int u = 0; u < WK_BOUNCE / 64; ++u) s_b[u * 64 + lane] = swap ? 1.0 - v[u] : v[u];
+            __syncthreads();
+            // pick up the photons of this cell that lie in the chunk
+            const int64_t rel = c0 - off;       // register index of the chunk's first photon
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                int64_t k = r - rel;
+                if (r < n && k >= 0 && k < m) lc.w[r] = s_b[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RL; ++r)
+            if (r < n) lc.w[r] = lc.tail(r);
+    }
+
+    // first pass of the schedule by the lanes
+    if (have) {
+        const double g = (guess ? guess[cell] : guess0) - 1, b = (beta ? beta[cell] : beta0) - 1;
+        if (bad) {
+            alpha[cell] = qnan();
+            if (ts) ts[cell] = qnan();
+            if (flags) flags[cell] = GODOT_F_FAILED;
+        } else if (big) {
+            int slot = atomicAdd(&q_count[0], 1);
+            q_cell[0][slot] = (short)lane;
+            q_depth[0][slot] = 0;
+            q_g[0][slot] = g;
+            q_b[0][slot] = b;
+        } else {
+            double a;
+            bool at_zero;
+            if (fit_attempt(lc, S, g, b, a, at_zero)) {
+                a = at_zero ? 0.0 : a + 1;
+                alpha[cell] = a;
+                if (ts) ts[cell] = test_statistic(lc, S, a);
+                if (flags) flags[cell] = at_zero ? GODOT_F_AT_ZERO : 0;
+            } else {
+                int slot = atomicAdd(&q_count[0], 1);
+                q_cell[0][slot] = (short)lane;
+                q_depth[0][slot] = 1;
+                q_g[0][slot] = (a + 1) - 1;
+                q_b[0][slot] = (b + 1) - 1;
+            }
+        }
+    }
+    // queue rounds: 16-lane teams, four cells at a time
+    constexpr int QT = 16;
+    const int team = lane / QT, tlane = lane % QT;
+    for (int round = 0; round < 5; ++round) {
+        const int qr = round & 1, qw = (round + 1) & 1;
+        __syncthreads();
+        const int nq = q_count[qr];
+        if (nq == 0) break;
+        __syncthreads();
+        if (lane == 0) q_count[qw] = 0;
+        __syncthreads();
+        for (int e = team; e < nq; e += 64 / QT) {
+            const int cl = q_cell[qr][e];
+            const int depth = q_depth[qr][e];
+            const int64_t c = cell0 + cl;
+            const double g = q_g[qr][e], b = q_b[qr][e];
+            const int64_t l = p.lo[c], h = p.hi[c];
+            const double Sc = swap ? p.B[c] : p.S[c];
+            CellData<QT, 4> cd;
+            cd.load(p.we + l, h - l, tlane, swap);
+            int fl = depth << 1;
+            double a, t = 0.0;
+            bool at_zero, done = true;
+            if (fit_attempt(cd, Sc, g, b, a, at_zero)) {
+                if (at_zero) {
+                    a = 0.0;
+                    fl |= GODOT_F_AT_ZERO;
+                } else {
+                    a = a + 1;
+                }
+            } else if (depth > 2) {
+                a = max_numerical(cd, Sc, fl);
+            } else {
+                if (tlane == 0) {
+                    int slot = atomicAdd(&q_count[qw], 1);
+                    q_cell[qw][slot] = (short)cl;
+                    q_depth[qw][slot] = (short)(depth + 1);
+                    q_g[qw][slot] = (a + 1) - 1;
+                    q_b[qw][slot] = (b + 1) - 1;
+                }
+                done = false;
+            }
+            if (done) {
+                if (ts) t = (fl & GODOT_F_FAILED) ? qnan() : test_statistic(cd, Sc, a);
+                if (tlane == 0) {
+                    alpha[c] = a;
+                    if (ts) ts[c] = t;
+                    if (flags) flags[c] = fl;
+                }
+            }
+        }
+    }
+}
+
 template <int T, int R>
 __global__ __launch_bounds__(256) void cell_loglike_kernel(CellArgs p, const double *alpha, double *out)
 {
@@ -524,8 +788,8 @@ __global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *w
 // ---------------------------------------------------------------------------
 // get_beta_max (core.py:741-823) and log_profile_likelihood (core.py:391-406)
 // ---------------------------------------------------------------------------
-template <int T, int R>
-__device__ double fit_beta(const CellData<T, R> &cd, double B, double alpha, double guess, int &flags)
+template <class CD>
+__device__ double fit_beta(const CD &cd, double B, double alpha, double guess, int &flags)
 {
     if (isnan(alpha)) return 1.0;
     if (cd.n == 0) return 0.0;
@@ -644,8 +908,8 @@ struct Support {
     double amin, amax, llmax;
 };
 
-template <int T, int R>
-__device__ Support support_search(const CellData<T, R> &cd, double S, double aopt, double dlogl,
+template <class CD>
+__device__ Support support_search(const CD &cd, double S, double aopt, double dlogl,
                                   bool include_zero)
 {
     Support r;
@@ -1074,8 +1338,23 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_fit: swap needs B");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
-    DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts,
-                  flags);
+    if ((double)nph <= 28.0 * (double)ncell) {
+        // sparse cells: one lane per cell; registers per lane about the mean plus two sigma (Poisson)
+        double mean = (double)nph / (double)ncell;
+        dim3 grid((unsigned)ceil_div(ncell, 64));
+        if (mean <= 4.0)
+            hipLaunchKernelGGL((cell_fit_wave_kernel<8>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
+                               alpha, ts, flags);
+        else if (mean <= 10.0)
+            hipLaunchKernelGGL((cell_fit_wave_kernel<16>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
+                               alpha, ts, flags);
+        else
+            hipLaunchKernelGGL((cell_fit_wave_kernel<32>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
+                               alpha, ts, flags);
+    } else {
+        DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts,
+                      flags);
+    }
     GODOT_LAUNCH_CHECK("godot_cell_fit");
     return GODOT_OK;
 }
