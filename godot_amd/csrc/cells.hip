@@ -373,7 +373,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     double a = g;
     if (B0 && g == 0.0) {
         cd.template sums<3>([](double w, double (&s)[3]) {
-            s[0] += w * rcp_fast(1.0 - w);
+            s[0] += w * rcp_fast1(1.0 - w);
             s[1] += w;
             s[2] += w * w;
         }, acc);
@@ -390,7 +390,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
             return true;
         }
         cd.template sums<2>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast(fma(g, w, t2of(w)));
+            double r = w * rcp_fast1(fma(g, w, t2of(w)));
             s[0] += r;
             s[1] += r * r;
         }, reinterpret_cast<double (&)[2]>(acc));
@@ -400,7 +400,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     if (a < 0 - 1) a = 0.2 - 1;
     auto pass2 = [&](double a_) {
         cd.template sums<2>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast(fma(a_, w, t2of(w)));
+            double r = w * rcp_fast1(fma(a_, w, t2of(w)));
             s[0] += r;
             s[1] += r * r;
         }, reinterpret_cast<double (&)[2]>(acc));
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void cell_fit_kernel(CellArgs p, const double 
 // served by 16-lane teams (they read the weights again; L2 holds them).
 // Small LDS and a 128-register cap keep four wavefronts per SIMD resident so
 // that the load latency of one hides behind the arithmetic of the others.
-constexpr int WK_BOUNCE = 512;   // photons per bounce chunk (4 KB)
+constexpr int WK_BOUNCE = 1024;   // photons per bounce chunk (8 KB)
 
 template <int RL>
 __global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const double *guess, double guess0,
@@ -637,9 +637,12 @@ __global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const 
         const int64_t base = __shfl((long long)lo, 0, WAVE);
         const int nlast = (int)((p.ncell - cell0) < 64 ? (p.ncell - cell0) : 64) - 1;
         const int64_t end = __shfl((long long)hi, nlast, WAVE);
-        const int64_t off = lo - base;          // this cell's first photon in the run
-        for (int64_t c0 = 0; c0 < end - base; c0 += WK_BOUNCE) {
-            const int m = (int)((end - base - c0) < WK_BOUNCE ? (end - base - c0) : WK_BOUNCE);
+        const int64_t span = end - base;
+        // this cell's first photon in the run (cells beyond 2^31 photons from the base hold none here)
+        const int64_t off64 = lo - base;
+        const int off = (off64 > 0x3fffffff) ? 0x3fffffff : (int)off64;
+        for (int64_t c0 = 0; c0 < span; c0 += WK_BOUNCE) {
+            const int m = (int)((span - c0) < WK_BOUNCE ? (span - c0) : WK_BOUNCE);
             double v[WK_BOUNCE / 64];
 #pragma unroll
             for (int u = 0; u < WK_BOUNCE / 64; ++u) {
@@ -650,13 +653,18 @@ __global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const 
 #pragma unroll
             for (int u = 0; u < WK_BOUNCE / 64; ++u) s_b[u * 64 + lane] = swap ? 1.0 - v[u] : v[u];
             __syncthreads();
-            // pick up the photons of this cell that lie in the chunk
-            const int64_t rel = c0 - off;       // register index of the chunk's first photon
+            // registers [r_lo, r_hi) of this lane are photons [r_lo + shift, r_hi + shift) of the chunk
+            const int c0i = (c0 > 0x3fffffff) ? 0x3fffffff : (int)c0;
+            const int shift = off - c0i;        // chunk index of the cell's photon 0
+            int r_lo = -shift;
+            r_lo = r_lo < 0 ? 0 : r_lo;
+            int r_hi = m - shift;
+            r_hi = r_hi > n ? n : r_hi;
+            const unsigned width = r_hi > r_lo ? (unsigned)(r_hi - r_lo) : 0u;
+            const double *src = s_b + shift;
 #pragma unroll
-            for (int r = 0; r < RL; ++r) {
-                int64_t k = r - rel;
-                if (r < n && k >= 0 && k < m) lc.w[r] = s_b[k];
-            }
+            for (int r = 0; r < RL; ++r)
+                if ((unsigned)(r - r_lo) < width) lc.w[r] = src[r];
         }
     } else {
 #pragma unroll

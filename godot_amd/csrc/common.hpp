@@ -87,6 +87,14 @@ __device__ __forceinline__ double rcp_fast(double d)
     return fma(x, e, x);
 }
 
+// One Newton step only: relative error about 2^-44, for intermediate passes.
+__device__ __forceinline__ double rcp_fast1(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    return fma(x, e, x);
+}
+
 // Python's max(a, b): b only if b > a (so a NaN second argument yields a).
 __device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
 __device__ __forceinline__ double pymin(double a, double b) { return (b < a) ? b : a; }
