@@ -168,8 +168,15 @@ def main():
     k_ms = event_time_ms(step, max(20, min(args.steps, 200)), stream)
     alg_bytes = 8 * nph_in + 8 * (ncell + 1) + 16 * ncell + 16 * ncell
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes (taken separately with rocprofv3 on this same
+    # workload and committed under profiles/; null when the workload differs from the one profiled)
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'r1_cell_fit_traffic.json')
+    if os.path.exists(tpath) and args.nph == 10_000_000 and args.tcell == 600.0 and args.years == 10.0:
+        with open(tpath) as f:
+            traffic = json.load(f).get('traffic_bytes_per_launch')
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, kernel='cell_fit_kernel',
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, kernel='cell_fit_wave_kernel',
                     algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=k_ms)
 
     extra = dict(ncell=ncell, photons_in_cells=nph_in,
@@ -181,6 +188,15 @@ def main():
         extra['profile_grid'] = dict(cells_per_s=ncell / (p_ms * 1e-3), ms=p_ms,
                                      log_evals_per_s=200.0 * nph_in / (p_ms * 1e-3))
         torch.cuda.empty_cache()
+        # dense cells (the per-source shape of C1 / C5): same photons in 2-hour cells
+        dcells = data.get_cells(tcell=7200., use_barycenter=False, quiet=True)
+        dcr = dcells.ranges()
+        ops.cell_fit(dcr)
+        d_ms = event_time_ms(lambda: ops.cell_fit(dcr), 20, stream)
+        dn = int((dcr.hi - dcr.lo).sum().cpu())
+        extra['dense_cells'] = dict(ncell=dcr.ncell, photons_per_cell=dn / max(dcr.ncell, 1), ms=d_ms,
+                                    cells_per_s=dcr.ncell / (d_ms * 1e-3),
+                                    algorithmic_GBps=(8 * dn + 40 * dcr.ncell) / (d_ms * 1e-3) / 1e9)
         # Z^2_2 search: 1e6 photons x 2^21 trial frequencies (a slice of C4's 1e8)
         zs = synth.synth(1_000_000, years=1.0, seed=17)
         zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)

@@ -505,7 +505,7 @@ __device__ __forceinline__ bool cell_setup(const CellArgs &p, int64_t &cell, int
 // (cell, new start) to a queue in LDS and the workgroup then serves the queue
 // with densely packed teams that reload the cell's weights (L2-resident).
 template <int T, int R>
-__global__ __launch_bounds__(256) void cell_fit_kernel(CellArgs p, const double *guess, double guess0,
+__global__ __launch_bounds__(256, 4) void cell_fit_kernel(CellArgs p, const double *guess, double guess0,
                                                        const double *beta, double beta0,
                                                        double *alpha, double *ts, int32_t *flags)
 {
@@ -1289,14 +1289,21 @@ __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop
 // ---------------------------------------------------------------------------
 namespace {
 
-// team size from the mean number of photons per cell
+// Team shape (T lanes x R registers) from the mean number of photons per cell:
+// the smallest capacity T*R that holds the mean plus four (Poisson) sigma, so
+// that almost every cell stays in registers, with as few lanes per cell as
+// possible (fewer reduction steps, more cells per wavefront).
 inline int pick_team(int64_t nph, int64_t ncell)
 {
     double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
-    if (mean <= 6) return 4;
-    if (mean <= 48) return 8;
-    if (mean <= 200) return 32;
-    return 64;
+    double need = mean + 4.0 * sqrt(mean) + 8.0;
+    if (need <= 32) return 0;     // 4 x 8
+    if (need <= 64) return 1;     // 8 x 8
+    if (need <= 128) return 2;    // 8 x 16
+    if (need <= 256) return 3;    // 8 x 32
+    if (need <= 512) return 4;    // 16 x 32
+    if (need <= 1024) return 5;   // 32 x 32
+    return 6;                     // 64 x 32, larger cells stream from L2
 }
 
 inline int check_cells(const void *we, int64_t nph, const void *lo, const void *hi, int64_t ncell,
@@ -1310,25 +1317,22 @@ inline int check_cells(const void *we, int64_t nph, const void *lo, const void *
     return GODOT_OK;
 }
 
-#define DISPATCH_TEAM(T_, KERNEL, GRID_ARGS, ...)                                          \
+#define DISPATCH_ONE(T_, R_, KERNEL, ...)                                                  \
+    {                                                                                       \
+        dim3 grid((unsigned)ceil_div(ncell, 256 / (T_)));                                   \
+        hipLaunchKernelGGL((KERNEL<T_, R_>), grid, dim3(256), 0, st, __VA_ARGS__);          \
+    }                                                                                       \
+    break;
+#define DISPATCH_TEAM(CFG_, KERNEL, GRID_ARGS, ...)                                         \
     do {                                                                                    \
-        switch (T_) {                                                                       \
-        case 4: {                                                                           \
-            dim3 grid((unsigned)ceil_div(ncell, 256 / 4));                                  \
-            hipLaunchKernelGGL((KERNEL<4, 8>), grid, dim3(256), 0, st, __VA_ARGS__);        \
-        } break;                                                                            \
-        case 8: {                                                                           \
-            dim3 grid((unsigned)ceil_div(ncell, 256 / 8));                                  \
-            hipLaunchKernelGGL((KERNEL<8, 8>), grid, dim3(256), 0, st, __VA_ARGS__);        \
-        } break;                                                                            \
-        case 32: {                                                                          \
-            dim3 grid((unsigned)ceil_div(ncell, 256 / 32));                                 \
-            hipLaunchKernelGGL((KERNEL<32, 8>), grid, dim3(256), 0, st, __VA_ARGS__);       \
-        } break;                                                                            \
-        default: {                                                                          \
-            dim3 grid((unsigned)ceil_div(ncell, 256 / 64));                                 \
-            hipLaunchKernelGGL((KERNEL<64, 16>), grid, dim3(256), 0, st, __VA_ARGS__);      \
-        } break;                                                                            \
+        switch (CFG_) {                                                                     \
+        case 0: DISPATCH_ONE(4, 8, KERNEL, __VA_ARGS__)                                     \
+        case 1: DISPATCH_ONE(8, 8, KERNEL, __VA_ARGS__)                                     \
+        case 2: DISPATCH_ONE(8, 16, KERNEL, __VA_ARGS__)                                    \
+        case 3: DISPATCH_ONE(8, 32, KERNEL, __VA_ARGS__)                                    \
+        case 4: DISPATCH_ONE(16, 32, KERNEL, __VA_ARGS__)                                   \
+        case 5: DISPATCH_ONE(32, 32, KERNEL, __VA_ARGS__)                                   \
+        default: DISPATCH_ONE(64, 32, KERNEL, __VA_ARGS__)                                  \
         }                                                                                   \
     } while (0)
 
