@@ -49,6 +49,10 @@ SIGNATURES = {
     'godot_lightcurve_rows': (c_int, [c_f64p] * 7 + [c_i64, c_f64, c_f64p, c_stream]),
     'godot_cell_beta_max': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,
                                              c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_cell_fit_joint': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,
+                                              c_int, c_f64p, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_cell_logpdf_profile': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_int, c_int,
+                                                   c_f64p, c_f64p, c_i32p, c_stream]),
     'godot_exposure_table_bytes': (c_size, [c_i64]),
     'godot_exposure_table': (c_int, [c_f64p] * 4 + [c_i64, c_f64, c_f64, c_ws, c_size, c_stream]),
     'godot_exposure_workspace_bytes': (c_size, [c_i64]),

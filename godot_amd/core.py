@@ -302,7 +302,9 @@ class CellLogLikelihood(object):
 
     def get_max(self, guess=1, beta=1, profile_background=False):
         if profile_background:
-            raise NotImplementedError('joint (alpha, beta) fit is not built yet')
+            a, b, _, fl = ops.cell_fit_joint(self._cr, guess_a=float(guess), guess_b=float(beta),
+                                             swap=self._swap)
+            return np.array([_scalar(a), _scalar(b)])
         a, _, fl = ops.cell_fit(self._cr, guess=float(guess), beta=float(beta), swap=self._swap,
                                 want_ts=False)
         a = _scalar(a)
@@ -312,10 +314,14 @@ class CellLogLikelihood(object):
         return 0 if (int(fl.cpu()[0]) & 1) else a
 
     def get_ts(self, aopt=None, profile_background=False):
-        if profile_background:
-            raise NotImplementedError('profile-background TS is not built yet')
         if self.S == 0:
             return 0
+        if profile_background:
+            if aopt is None:
+                aopt = self.get_max(profile_background=True)[0]
+            if aopt == 0:
+                return 0
+            return 2 * (self.log_profile_likelihood(aopt) - self.log_profile_likelihood(0))
         g = 1.0 if aopt is None else float(aopt)
         if aopt is None:
             a, ts, _ = ops.cell_fit(self._cr, swap=self._swap)
@@ -328,9 +334,13 @@ class CellLogLikelihood(object):
 
     def get_logpdf(self, aopt=None, dlogl=20, npt=100, include_zero=False,
                    profile_background=False):
-        if profile_background:
-            raise NotImplementedError('profile-background log pdf is not built yet')
         at = None if aopt is None else self._t(aopt)
+        if profile_background:
+            dom, cod, fl = ops.cell_logpdf_profile(self._cr, aopt=at, dlogl=dlogl, npt=npt,
+                                                   swap=self._swap)
+            if int(fl.cpu()[0]) & 0x10:
+                raise ValueError('profile likelihood grid failed (no bracket or no convergence)')
+            return _np(dom[0]), _np(cod[0])
         dom, cod, fl = ops.cell_logpdf(self._cr, aopt=at, dlogl=dlogl, npt=npt,
                                        include_zero=include_zero, swap=self._swap)
         return _np(dom[0]), _np(cod[0])
@@ -363,8 +373,6 @@ class CellsLogLikelihood(object):
     the raw light curve (reference core.py:1070-1098, 1227-1336)."""
 
     def __init__(self, cells, profile_background=False, swap=False, reverse=False, device=None):
-        if profile_background:
-            raise NotImplementedError('profile_background=True is not built yet')
         batch = _as_batch(cells, device=device)
         if reverse:
             batch = batch[::-1] if not isinstance(batch, CellBatch) else CellBatch(
@@ -373,10 +381,17 @@ class CellsLogLikelihood(object):
                 batch.sexp.flip(0).contiguous(), batch.bexp.flip(0).contiguous())
         self.cells = batch
         self._swap = bool(swap)
-        self.profile_background = False
+        self.profile_background = bool(profile_background)
         self._cr = batch.ranges()
-        self._dom_d, self._cod_d, self._flags = ops.cell_logpdf(self._cr, dlogl=30, npt=200,
-                                                                swap=self._swap)
+        if profile_background:
+            self._dom_d, self._cod_d, self._flags = ops.cell_logpdf_profile(
+                self._cr, dlogl=30, npt=200, swap=self._swap)
+            if bool((self._flags & 0x10).any().cpu()):
+                # the reference raises out of its constructor in this case (core.py:818)
+                raise ValueError('Did not converge while profiling the background of a cell')
+        else:
+            self._dom_d, self._cod_d, self._flags = ops.cell_logpdf(self._cr, dlogl=30, npt=200,
+                                                                    swap=self._swap)
         self._dom_h = self._cod_h = None
         self.fitness_vals = None
 
@@ -403,6 +418,15 @@ class CellsLogLikelihood(object):
     def get_flux_all(self, conf=[0.05, 0.95]):
         """(aopt, ts, xlo, xhi) device tensors for every cell."""
         ag, xlo, xhi = ops.profile_quantiles(self._dom_d, self._cod_d, conf[0], conf[1])
+        if self.profile_background:
+            # core.py:1231-1245: beta guess from the profile, joint refit, profile TS
+            bg, _, _ = ops.cell_beta_max(self._cr, ag, swap=self._swap, want_logl=False)
+            aopt, _, _, _ = ops.cell_fit_joint(self._cr, guess_a=ag, guess_b=bg, swap=self._swap)
+            _, lp1, _ = ops.cell_beta_max(self._cr, aopt, swap=self._swap)
+            _, lp0, _ = ops.cell_beta_max(self._cr, 0.0, swap=self._swap)
+            ts = 2 * (lp1 - lp0)
+            ts = torch.where((aopt == 0) | (self._cr.S == 0), torch.zeros_like(ts), ts)
+            return aopt, ts, xlo, xhi
         aopt, ts, _ = ops.cell_fit(self._cr, guess=ag, beta=1.0, swap=self._swap)
         return aopt, ts, xlo, xhi
 
@@ -415,6 +439,7 @@ class CellsLogLikelihood(object):
         sub._dom_d = self._dom_d[idx:idx + 1].contiguous()
         sub._cod_d = self._cod_d[idx:idx + 1].contiguous()
         sub._swap = self._swap
+        sub.profile_background = self.profile_background
         aopt, ts, xlo, xhi = sub.get_flux_all(conf)
         return _scalar(aopt), _scalar(ts), np.array([_scalar(xlo), _scalar(xhi)])
 
@@ -427,6 +452,9 @@ class CellsLogLikelihood(object):
             if np.all((alpha_h >= dom[:, 0]) & (alpha_h <= dom[:, -1])):
                 return sum(np.interp(a, d, c) for a, d, c in zip(alpha_h, dom, cod))
         at = _to_dev(alpha, self.cells.device)
+        if self.profile_background:
+            _, lp, _ = ops.cell_beta_max(self._cr, at, swap=self._swap)
+            return float(lp.sum().cpu())
         return float(ops.cell_loglike(self._cr, at, swap=self._swap).sum().cpu())
 
     def get_raw_lightcurve(self, tsmin=4):

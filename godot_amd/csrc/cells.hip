@@ -10,494 +10,10 @@
 // then come from L2, which a cell of that size still fits).  Divisions are a
 // hardware reciprocal estimate plus two Newton steps (the operands are never
 // near the ends of the exponent range), reductions use DPP lane permutes.
-#include "common.hpp"
+
+#include "cells_common.hpp"
 
 namespace {
-
-struct CellArgs {
-    const double *we;
-    int64_t nph;
-    const int64_t *lo;
-    const int64_t *hi;
-    const double *S;
-    const double *B;
-    int64_t ncell;
-    int swap;
-};
-
-// Weights of one cell as seen by one lane of its team.
-template <int T, int R>
-struct CellData {
-    double w[R];
-    const double *p;
-    int64_t n;
-    int lane;
-    bool in_regs;
-    bool swap;
-
-    __device__ __forceinline__ double ld(int64_t i) const
-    {
-        double v = p[i];
-        return swap ? 1.0 - v : v;
-    }
-
-    __device__ __forceinline__ void load(const double *base, int64_t n_, int lane_, bool swap_)
-    {
-        p = base;
-        n = n_;
-        lane = lane_;
-        swap = swap_;
-        in_regs = n <= (int64_t)T * R;
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                int64_t i = lane + (int64_t)r * T;
-                w[r] = (i < n) ? ld(i) : 0.0;
-            }
-        }
-    }
-
-    // acc[k] = sum over the cell's photons of what f adds, for k < NS.
-    template <int NS, class F>
-    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
-    {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) f(w[r], acc);
-        } else {
-            for (int64_t i = lane; i < n; i += T) f(ld(i), acc);
-        }
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
-    }
-
-    // sum over the cell of log(t_i) and of g_i, where f(w, t, g) yields the
-    // positive t_i and the addend g_i of one photon.  The logarithms are taken
-    // of the running product (mantissa renormalised into [0.5, 1) every eight
-    // factors, exponent kept as an integer): one log per cell, not per photon.
-    template <class F>
-    __device__ __forceinline__ void logsum(F f, double &logs, double &gsum) const
-    {
-        double pr = 1.0, gs = 0.0;
-        int ex = 0;
-        auto renorm = [&]() {
-            ex += __builtin_amdgcn_frexp_exp(pr);
-            pr = __builtin_amdgcn_frexp_mant(pr);
-        };
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) {
-                    double t, g;
-                    f(w[r], t, g);
-                    pr *= t;
-                    gs += g;
-                    if ((r & 7) == 7) renorm();
-                }
-        } else {
-            int k = 0;
-            for (int64_t i = lane; i < n; i += T) {
-                double t, g;
-                f(ld(i), t, g);
-                pr *= t;
-                gs += g;
-                if ((++k & 7) == 0) renorm();
-            }
-        }
-        renorm();
-        pr = team_prod<T>(pr);   // factors in [0.5, 1): at worst 2^-64
-        ex = team_sum_i32<T>(ex);
-        gsum = team_sum<T>(gs);
-        logs = log(pr) + (double)ex * 0.6931471805599453;
-    }
-
-    // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
-    // ratio of the two renormalised products
-    template <class F>
-    __device__ __forceinline__ double logratio(F f) const
-    {
-        double p1 = 1.0, p2 = 1.0;
-        int ex = 0;
-        auto renorm = [&]() {
-            ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
-            p1 = __builtin_amdgcn_frexp_mant(p1);
-            p2 = __builtin_amdgcn_frexp_mant(p2);
-        };
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) {
-                    double t1, t2;
-                    f(w[r], t1, t2);
-                    p1 *= t1;
-                    p2 *= t2;
-                    if ((r & 7) == 7) renorm();
-                }
-        } else {
-            int k = 0;
-            for (int64_t i = lane; i < n; i += T) {
-                double t1, t2;
-                f(ld(i), t1, t2);
-                p1 *= t1;
-                p2 *= t2;
-                if ((++k & 7) == 0) renorm();
-            }
-        }
-        renorm();
-        p1 = team_prod<T>(p1);
-        p2 = team_prod<T>(p2);
-        ex = team_sum_i32<T>(ex);
-        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
-    }
-
-    template <class F>
-    __device__ __forceinline__ double maxof(F f) const
-    {
-        double m = -INFINITY;
-        if (in_regs) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) m = fmax(m, f(w[r]));
-        } else {
-            for (int64_t i = lane; i < n; i += T) m = fmax(m, f(ld(i)));
-        }
-        return team_max<T>(m);
-    }
-};
-
-// Weights of one cell owned by ONE lane: the first R weights live in
-// registers, zero-padded.  A zero weight adds nothing to any sum of the fit
-// (w/(t2 + a w) = 0) and multiplies the likelihood products by exactly 1, so
-// the register part needs no predication.  Photons beyond R (rare) are read
-// from memory in every pass.  Same interface as CellData; no cross-lane
-// traffic.
-template <int R>
-struct LaneCell {
-    double w[R];
-    const double *g;   // the cell's weights in global memory (for the tail)
-    int n;
-    bool swap;
-
-    __device__ __forceinline__ double tail(int j) const
-    {
-        double v = g[j];
-        return swap ? 1.0 - v : v;
-    }
-
-    template <int NS, class F>
-    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
-    {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) f(w[r], acc);
-        for (int j = R; j < n; ++j) f(tail(j), acc);
-    }
-
-    template <class F>
-    __device__ __forceinline__ void logsum(F f, double &logs, double &gsum) const
-    {
-        double pr = 1.0, gs = 0.0;
-        int ex = 0;
-        auto step = [&](double wv, int j) {
-            double t, g;
-            f(wv, t, g);
-            pr *= t;
-            gs += g;
-            if ((j & 7) == 7) {
-                ex += __builtin_amdgcn_frexp_exp(pr);
-                pr = __builtin_amdgcn_frexp_mant(pr);
-            }
-        };
-#pragma unroll
-        for (int r = 0; r < R; ++r) step(w[r], r);
-        for (int j = R; j < n; ++j) step(tail(j), j);
-        ex += __builtin_amdgcn_frexp_exp(pr);
-        pr = __builtin_amdgcn_frexp_mant(pr);
-        gsum = gs;
-        logs = log(pr) + (double)ex * 0.6931471805599453;
-    }
-
-    template <class F>
-    __device__ __forceinline__ double logratio(F f) const
-    {
-        double p1 = 1.0, p2 = 1.0;
-        int ex = 0;
-        auto step = [&](double wv, int j) {
-            double t1, t2;
-            f(wv, t1, t2);
-            p1 *= t1;
-            p2 *= t2;
-            if ((j & 7) == 7) {
-                ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
-                p1 = __builtin_amdgcn_frexp_mant(p1);
-                p2 = __builtin_amdgcn_frexp_mant(p2);
-            }
-        };
-#pragma unroll
-        for (int r = 0; r < R; ++r) step(w[r], r);
-        for (int j = R; j < n; ++j) step(tail(j), j);
-        ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
-        p1 = __builtin_amdgcn_frexp_mant(p1);
-        p2 = __builtin_amdgcn_frexp_mant(p2);
-        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
-    }
-
-    template <class F>
-    __device__ __forceinline__ double maxof(F f) const
-    {
-        double m = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (r < n) m = fmax(m, f(w[r]));
-        for (int j = R; j < n; ++j) m = fmax(m, f(tail(j)));
-        return m;
-    }
-};
-
-// ---------------------------------------------------------------------------
-// get_max with the background level fixed: reference core.py:632-691.
-// g = guess - 1, b = beta - 1 (the reference's zero-based parameters).
-// ---------------------------------------------------------------------------
-
-// f(a) = sum w/(t2 + a w) - S with t2 = 1 + b (1 - w)
-template <class CD>
-__device__ double score(const CD &cd, double a, double b, double S)
-{
-    double acc[1];
-    cd.template sums<1>([=](double w, double (&s)[1]) {
-        double t2 = 1.0 + b * (1.0 - w);
-        s[0] += w * rcp_fast(t2 + a * w);
-    }, acc);
-    return acc[0] - S;
-}
-
-// scipy.optimize.brentq (Zeros/brentq.c) on the score function with beta = 1,
-// as the reference's get_max_numerical uses it (core.py:728-739).
-template <class CD>
-__device__ __noinline__ double max_numerical(const CD &cd, double S, int &flags)
-{
-    flags |= GODOT_F_BRENT;
-    if (score(cd, -1.0, 0.0, S) < 0) {
-        flags |= GODOT_F_AT_ZERO;
-        return 0.0;
-    }
-    double a0 = -1.0, amax = 0.0;
-    for (int i = 0; i < 12; ++i) {
-        if (score(cd, amax, 0.0, S) < 0) break;
-        a0 = amax;
-        amax = 2 * amax + 1;
-    }
-    const double xtol = 1e-3, rtol = 8.881784197001252e-16;
-    double xpre = a0, xcur = amax, xblk = 0, fblk = 0, spre = 0, scur = 0;
-    double fpre = score(cd, xpre, 0.0, S);
-    double fcur = score(cd, xcur, 0.0, S);
-    if (fpre == 0) return xpre + 1;
-    if (fcur == 0) return xcur + 1;
-    if (signbit(fpre) == signbit(fcur)) {
-        flags |= GODOT_F_FAILED;   // the reference raises ValueError here
-        return qnan();
-    }
-    for (int it = 0; it < 100; ++it) {
-        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
-            xblk = xpre;
-            fblk = fpre;
-            spre = scur = xcur - xpre;
-        }
-        if (fabs(fblk) < fabs(fcur)) {
-            xpre = xcur; xcur = xblk; xblk = xpre;
-            fpre = fcur; fcur = fblk; fblk = fpre;
-        }
-        double delta = (xtol + rtol * fabs(xcur)) / 2;
-        double sbis = (xblk - xcur) / 2;
-        if (fcur == 0 || fabs(sbis) < delta) return xcur + 1;
-        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
-            double stry;
-            if (xpre == xblk) {
-                stry = -fcur * (xcur - xpre) / (fcur - fpre);
-            } else {
-                double dpre = (fpre - fcur) / (xpre - xcur);
-                double dblk = (fblk - fcur) / (xblk - xcur);
-                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
-            }
-            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
-                spre = scur;
-                scur = stry;
-            } else {
-                spre = sbis;
-                scur = sbis;
-            }
-        } else {
-            spre = sbis;
-            scur = sbis;
-        }
-        xpre = xcur;
-        fpre = fcur;
-        if (fabs(scur) > delta) xcur += scur;
-        else xcur += (sbis > 0 ? delta : -delta);
-        fcur = score(cd, xcur, 0.0, S);
-    }
-    flags |= GODOT_F_FAILED;
-    return qnan();
-}
-
-template <class CD, bool B0>
-__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero);
-
-// One pass of the fixed schedule (core.py:639-680) from the zero-based start
-// values g = guess - 1, b = beta - 1.  Returns true when the result `a` (zero-
-// based) is final, false when the reference would call itself again with
-// guess = a + 1 (core.py:684-689).
-template <class CD>
-__device__ bool fit_attempt(const CD &cd, double S, double g, double b, double &a_out,
-                            bool &at_zero)
-{
-    // background level fixed at its nominal value (beta = 1): t2 = 1 exactly
-    if (b == 0.0) return fit_attempt_impl<CD, true>(cd, S, g, 0.0, a_out, at_zero);
-    return fit_attempt_impl<CD, false>(cd, S, g, b, a_out, at_zero);
-}
-
-
-template <class CD, bool B0>
-__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero)
-{
-    double acc[3];
-    at_zero = false;
-    // t2 = 1 + b (1 - w)
-    auto t2of = [=](double w) { return B0 ? 1.0 : 1.0 + b * (1.0 - w); };
-    // derivative at alpha = 0 (core.py:639-644) fused with the sums of the
-    // first Newton step when that starts from a = 0, b = 0 (w / 1 = w exactly)
-    double a = g;
-    if (B0 && g == 0.0) {
-        cd.template sums<3>([](double w, double (&s)[3]) {
-            s[0] += w * rcp_fast1(1.0 - w);
-            s[1] += w;
-            s[2] += w * w;
-        }, acc);
-        if (acc[0] - S < 0) {
-            at_zero = true;
-            a_out = -1.0;
-            return true;
-        }
-        a = a + (acc[1] - S) * rcp_fast(acc[2]);
-    } else {
-        if (score(cd, -1.0, b, S) < 0) {
-            at_zero = true;
-            a_out = -1.0;
-            return true;
-        }
-        cd.template sums<2>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast1(fma(g, w, t2of(w)));
-            s[0] += r;
-            s[1] += r * r;
-        }, reinterpret_cast<double (&)[2]>(acc));
-        a = a + (acc[0] - S) * rcp_fast(acc[1]);
-    }
-    // Newton 1 keeps away from zero flux (core.py:653-655)
-    if (a < 0 - 1) a = 0.2 - 1;
-    auto pass2 = [&](double a_) {
-        cd.template sums<2>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast1(fma(a_, w, t2of(w)));
-            s[0] += r;
-            s[1] += r * r;
-        }, reinterpret_cast<double (&)[2]>(acc));
-    };
-    // Newton 2 (core.py:658-664)
-    pass2(a);
-    a = a + (acc[0] - S) * rcp_fast(acc[1]);
-    if (a < 0.05 - 1) a = 0.05 - 1;
-    // Newton 3 (core.py:667-671)
-    pass2(a);
-    a = pymax(0.0 - 1, a + (acc[0] - S) * rcp_fast(acc[1]));
-    double alast = a;
-    // Halley (core.py:674-680)
-    {
-        double a_ = a;
-        cd.template sums<3>([=](double w, double (&s)[3]) {
-            double r = w * rcp_fast(fma(a_, w, t2of(w)));
-            double r2 = r * r;
-            s[0] += r;
-            s[1] += r2;
-            s[2] += r2 * r;
-        }, acc);
-    }
-    double f1 = acc[0] - S, f2 = acc[1], f3 = 2 * acc[2];
-    a = pymax(0.0 - 1, a + 2 * f1 * f2 * rcp_fast(2 * f2 * f2 - f1 * f3));
-    a_out = a;
-    // slow convergence or a far-away start: the reference tries again
-    return !((fabs(a - alast) > 0.05) || (fabs(g - a) > 10));
-}
-
-// get_max in place: used where a cell's weights are already loaded and no
-// other team can take over its restarts (the profile-grid kernel).
-template <class CD>
-__device__ double fit_alpha(const CD &cd, double S, double guess, double beta, int &flags)
-{
-    double g = guess - 1;
-    double b = beta - 1;
-    for (int depth = 0;; ++depth) {
-        flags = (flags & ~GODOT_F_DEPTH_MASK) | (depth << 1);
-        double a;
-        bool at_zero;
-        if (fit_attempt(cd, S, g, b, a, at_zero)) {
-            if (at_zero) {
-                flags |= GODOT_F_AT_ZERO;
-                return 0.0;
-            }
-            return a + 1;
-        }
-        if (depth > 2) return max_numerical(cd, S, flags);
-        g = (a + 1) - 1;
-        b = (b + 1) - 1;
-    }
-}
-
-// logL(alpha) = sum log(alpha w + (1 - w)) - S alpha   (core.py:353-364)
-template <class CD>
-__device__ double loglike(const CD &cd, double S, double alpha)
-{
-    double ls, unused;
-    cd.logsum([=](double w, double &t, double &g) {
-        t = fma(w, alpha, 1.0 - w);
-        g = 0.0;
-    }, ls, unused);
-    return ls - S * alpha;
-}
-
-// 2 (logL(aopt) - logL(0))   (core.py:982-994): the two sums of logarithms
-// are taken together as one log of a ratio of renormalised products.
-template <class CD>
-__device__ double test_statistic(const CD &cd, double S, double aopt)
-{
-    if (S == 0 || aopt == 0) return 0.0;
-    double dl = cd.logratio([=](double w, double &t1, double &t2) {
-        t2 = 1.0 - w;
-        t1 = fma(aopt, w, t2);
-    });
-    return 2 * (dl - S * aopt);
-}
-
-template <int T>
-__device__ __forceinline__ bool cell_setup(const CellArgs &p, int64_t &cell, int &lane,
-                                           int64_t &lo, int64_t &n, double &S, double &B, bool &bad)
-{
-    lane = threadIdx.x & (T - 1);
-    cell = (int64_t)blockIdx.x * (blockDim.x / T) + (threadIdx.x / T);
-    if (cell >= p.ncell) return false;
-    lo = p.lo[cell];
-    int64_t hi = p.hi[cell];
-    bad = (lo < 0) || (hi < lo) || (hi > p.nph);
-    n = bad ? 0 : hi - lo;
-    S = p.S[cell];
-    B = p.B ? p.B[cell] : 0.0;
-    if (p.swap) {
-        double t = S; S = B; B = t;
-    }
-    return true;
-}
 
 // One team per cell.  Cells whose first pass of the schedule asks for a
 // restart (about one in seven of sparse cells) are not iterated in place,
@@ -790,76 +306,6 @@ __global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *w
     if (lane == 0) {
         wsum[cell] = bad ? qnan() : acc[0];
         w2sum[cell] = bad ? qnan() : acc[1];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// get_beta_max (core.py:741-823) and log_profile_likelihood (core.py:391-406)
-// ---------------------------------------------------------------------------
-template <class CD>
-__device__ double fit_beta(const CD &cd, double B, double alpha, double guess, int &flags)
-{
-    if (isnan(alpha)) return 1.0;
-    if (cd.n == 0) return 0.0;
-    if (alpha == 0) return (double)cd.n / B;
-    double al = alpha - 1;
-    double g = guess - 1;
-    for (int depth = 0;; ++depth) {
-        flags = (flags & ~GODOT_F_DEPTH_MASK) | (depth << 1);
-        double acc[3];
-        cd.template sums<1>([](double w, double (&s)[1]) { s[0] += (1.0 - w) / w; },
-                            reinterpret_cast<double (&)[1]>(acc));
-        if (acc[0] < B * (1 + al)) {
-            flags |= GODOT_F_AT_ZERO;
-            return 0.0;
-        }
-        double b = g;
-        const double lows[3] = {0.2 - 1, 0.05 - 1, 0.02 - 1};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double b_ = b;
-            cd.template sums<2>([=](double w, double (&s)[2]) {
-                double iw = 1.0 - w;
-                double r = iw / ((1.0 + al * w) + b_ * iw);
-                s[0] += r;
-                s[1] += r * r;
-            }, reinterpret_cast<double (&)[2]>(acc));
-            b = b + (acc[0] - B) / acc[1];
-            b = pymax(lows[k], b);
-        }
-        double blast = b;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            double b_ = b;
-            cd.template sums<3>([=](double w, double (&s)[3]) {
-                double iw = 1.0 - w;
-                double r = iw / ((1.0 + al * w) + b_ * iw);
-                double r2 = r * r;
-                s[0] += r;
-                s[1] += r2;
-                s[2] += r2 * r;
-            }, acc);
-            double f1 = acc[0] - B, f2 = acc[1], f3 = 2 * acc[2];
-            double nb = pymax(0.0 - 1, b + 2 * f1 * f2 / (2 * f2 * f2 - f1 * f3));
-            if (k == 0) {
-                // step limiter of the first Halley iteration (core.py:799-803)
-                if (fabs(nb - b) > 10) b = 2 * b + 1;
-                else b = nb;
-                blast = b;
-            } else {
-                b = nb;
-            }
-        }
-        if ((fabs(b - blast) > 0.05) || (fabs(g - b) > 10) || (b == -1)) {
-            if (depth > 2) {
-                flags |= GODOT_F_FAILED;   // the reference raises ValueError
-                return qnan();
-            }
-            al = (al + 1) - 1;
-            g = (b + 1) - 1;
-            continue;
-        }
-        return b + 1;
     }
 }
 
@@ -1281,60 +727,6 @@ __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop
     r[4] = t;
     (void)S;
 }
-
-}   // namespace
-
-// ---------------------------------------------------------------------------
-// C ABI
-// ---------------------------------------------------------------------------
-namespace {
-
-// Team shape (T lanes x R registers) from the mean number of photons per cell:
-// the smallest capacity T*R that holds the mean plus four (Poisson) sigma, so
-// that almost every cell stays in registers, with as few lanes per cell as
-// possible (fewer reduction steps, more cells per wavefront).
-inline int pick_team(int64_t nph, int64_t ncell)
-{
-    double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
-    double need = mean + 4.0 * sqrt(mean) + 8.0;
-    if (need <= 32) return 0;     // 4 x 8
-    if (need <= 64) return 1;     // 8 x 8
-    if (need <= 128) return 2;    // 8 x 16
-    if (need <= 256) return 3;    // 8 x 32
-    if (need <= 512) return 4;    // 16 x 32
-    if (need <= 1024) return 5;   // 32 x 32
-    return 6;                     // 64 x 32, larger cells stream from L2
-}
-
-inline int check_cells(const void *we, int64_t nph, const void *lo, const void *hi, int64_t ncell,
-                       const char *fn)
-{
-    GODOT_REQUIRE(ncell >= 0 && nph >= 0, GODOT_E_INVALID, "%s: negative size", fn);
-    GODOT_REQUIRE(ncell < ((int64_t)1 << 31) * 4, GODOT_E_UNSUPPORTED, "%s: too many cells", fn);
-    if (ncell == 0) return GODOT_OK;
-    GODOT_REQUIRE(lo && hi, GODOT_E_INVALID, "%s: null cell range pointer", fn);
-    GODOT_REQUIRE(we || nph == 0, GODOT_E_INVALID, "%s: null weights pointer", fn);
-    return GODOT_OK;
-}
-
-#define DISPATCH_ONE(T_, R_, KERNEL, ...)                                                  \
-    {                                                                                       \
-        dim3 grid((unsigned)ceil_div(ncell, 256 / (T_)));                                   \
-        hipLaunchKernelGGL((KERNEL<T_, R_>), grid, dim3(256), 0, st, __VA_ARGS__);          \
-    }                                                                                       \
-    break;
-#define DISPATCH_TEAM(CFG_, KERNEL, GRID_ARGS, ...)                                         \
-    do {                                                                                    \
-        switch (CFG_) {                                                                     \
-        case 0: DISPATCH_ONE(4, 8, KERNEL, __VA_ARGS__)                                     \
-        case 1: DISPATCH_ONE(8, 8, KERNEL, __VA_ARGS__)                                     \
-        case 2: DISPATCH_ONE(8, 16, KERNEL, __VA_ARGS__)                                    \
-        case 3: DISPATCH_ONE(8, 32, KERNEL, __VA_ARGS__)                                    \
-        case 4: DISPATCH_ONE(16, 32, KERNEL, __VA_ARGS__)                                   \
-        case 5: DISPATCH_ONE(32, 32, KERNEL, __VA_ARGS__)                                   \
-        default: DISPATCH_ONE(64, 32, KERNEL, __VA_ARGS__)                                  \
-        }                                                                                   \
-    } while (0)
 
 }   // namespace
 

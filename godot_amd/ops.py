@@ -152,6 +152,36 @@ def cell_beta_max(cr, alpha, guess=1.0, swap=False, want_logl=True):
     return beta, lp, flags
 
 
+def cell_fit_joint(cr, guess_a=1.0, guess_b=1.0, swap=False):
+    """Joint (alpha, beta) maximum of every cell -> (alpha, beta, logL, flags)."""
+    n, dev = cr.ncell, cr.device
+    at, a0 = _per_cell(guess_a, n, dev, 'guess_a')
+    bt, b0 = _per_cell(guess_b, n, dev, 'guess_b')
+    alpha = torch.empty(n, dtype=F64, device=dev)
+    beta = torch.empty(n, dtype=F64, device=dev)
+    logl = torch.empty(n, dtype=F64, device=dev)
+    flags = torch.empty(n, dtype=I32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_fit_joint', *cr._head(), _p(cr.S), _p(cr.B), n, _p(at), a0, _p(bt), b0,
+                  int(bool(swap)), _p(alpha), _p(beta), _p(logl), _p(flags), _stream(dev))
+    return alpha, beta, logl, flags
+
+
+def cell_logpdf_profile(cr, aopt=None, dlogl=20., npt=100, swap=False):
+    n, dev = cr.ncell, cr.device
+    if aopt is not None:
+        _dev_check(aopt, F64, 'aopt')
+        if aopt.numel() != n:
+            raise ValueError('aopt must have one entry per cell')
+    dom = torch.empty((n, npt), dtype=F64, device=dev)
+    cod = torch.empty((n, npt), dtype=F64, device=dev)
+    flags = torch.empty(n, dtype=I32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_logpdf_profile', *cr._head(), _p(cr.S), _p(cr.B), n, _p(aopt),
+                  float(dlogl), int(npt), int(bool(swap)), _p(dom), _p(cod), _p(flags), _stream(dev))
+    return dom, cod, flags
+
+
 def cell_moments(we, lo, hi):
     _dev_check(we, F64, 'we')
     _dev_check(lo, I64, 'lo')

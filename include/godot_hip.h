@@ -124,6 +124,34 @@ int godot_cell_beta_max(const double *we, int64_t nph,
                         double *beta, double *logl_profile, int32_t *flags,
                         godot_stream_t stream);
 
+/* Joint maximum of logL(alpha, beta) over alpha >= 0, beta >= 0: the result of
+ * get_max(profile_background=True) (core.py:552-630).  The reference uses
+ * scipy's truncated-Newton search with ftol = 1e-3; this is a projected Newton
+ * iteration to convergence, so (alpha, beta) agree with the reference to that
+ * optimiser's tolerance and logL is never lower than the reference's by more
+ * than its own acceptance margin (2e-3, core.py:617-620).
+ *   guess_a/guess_b  per-cell starts or NULL for the scalars
+ *   logl             log_full_likelihood at the maximum (core.py:427-438), may be NULL */
+int godot_cell_fit_joint(const double *we, int64_t nph,
+                         const int64_t *lo, const int64_t *hi,
+                         const double *S, const double *B, int64_t ncell,
+                         const double *guess_a, double guess_a0,
+                         const double *guess_b, double guess_b0, int swap,
+                         double *alpha, double *beta, double *logl,
+                         int32_t *flags, godot_stream_t stream);
+
+/* Profile-likelihood grid with the background level free: _get_logpdf_profile
+ * (core.py:934-974): support limits by two Brent root finds on
+ * log_profile_likelihood - llmax + dlogl, then npt evaluations of
+ * log_profile_likelihood (each a get_beta_max).  aopt: per-cell flux to centre
+ * on (beta follows from get_beta_max) or NULL to start from the joint maximum. */
+int godot_cell_logpdf_profile(const double *we, int64_t nph,
+                              const int64_t *lo, const int64_t *hi,
+                              const double *S, const double *B, int64_t ncell,
+                              const double *aopt, double dlogl, int npt, int swap,
+                              double *dom, double *cod, int32_t *flags,
+                              godot_stream_t stream);
+
 /* ---- binning: Data.get_exposure / Data.get_cells, core.py:1792-1843, 2063-2206 */
 
 /* Running sums of the exposure table (np.cumsum at core.py:1826-1832) for the

@@ -353,6 +353,72 @@ class CellLike(object):
         return np.sum(np.log(t)) - self.S * (1 + a) - self.B * (1 + b)
 
 
+    # ------------------------------------------------------------------
+    # a7: joint (alpha, beta) maximum, core.py:552-630.  The optimiser is
+    # third-party (scipy.optimize.fmin_tnc, ftol=1e-3, maxfun=200; the
+    # reference pins no scipy version -- 1.15.3 is installed here): its
+    # result is defined only to its own tolerance, so parity for this entry
+    # is stated on logL (>= reference - 2e-3), not on (alpha, beta).
+    # ------------------------------------------------------------------
+    def get_max_profile(self, guess=1, beta=1):
+        from scipy.optimize import fmin_tnc
+        fn = lambda q: self.neg_logl_grad(q[0], q[1])
+        kw = dict(bounds=[[0, None], [0, None]], disp=0, ftol=1e-3, maxfun=200)
+        ok = lambda rc: not ((rc < 0) or (rc > 2))
+        rvals, _, rc = fmin_tnc(fn, [float(guess), float(beta)], **kw)
+        if ok(rc):
+            return rvals
+        guess, beta = rvals[0] + 1e-3, rvals[1] - 1e-3     # core.py:565-568
+        rvals, _, rc = fmin_tnc(fn, [guess, beta], **kw)
+        if ok(rc):
+            return rvals
+        oldrvals, oldlogl = rvals, fn(rvals)[0]
+        if rc == 3:                                          # core.py:585-587
+            newguess, newbeta = guess, beta
+        else:                                                # core.py:589-607
+            grid = np.asarray([0, 0.1, 0.3, 0.5, 1.0, 1.5, 2.0, 5.0, 10.0])
+            cogrid = np.asarray([self.log_profile_likelihood(x) for x in grid])
+            k = np.argmax(cogrid)
+            lo, hi = max(0, k - 1), min(k + 1, len(grid) - 1)
+            if abs(cogrid[hi] - cogrid[lo]) > 100:
+                grid = np.linspace(grid[lo], grid[hi], 20)
+                cogrid = np.asarray([self.log_profile_likelihood(x) for x in grid])
+            newguess = float(grid[np.argmax(cogrid)])
+            newbeta = float(max(0.1, self.get_beta_max(newguess)))
+        rvals, _, rc = fmin_tnc(fn, [newguess, newbeta], **kw)
+        if ok(rc) and fn(rvals)[0] > oldlogl:                # core.py:616-620
+            return oldrvals
+        return rvals
+
+    # _get_logpdf_profile, core.py:934-974
+    def get_logpdf_profile(self, aopt=None, dlogl=20, npt=100):
+        if aopt is None:
+            aopt, bopt = self.get_max_profile()
+        else:
+            bopt = self.get_beta_max(aopt)
+        llmax = self.log_full_likelihood(aopt, bopt)
+        f = lambda a: self.log_profile_likelihood(a) - llmax + dlogl
+        a0 = aopt
+        amin = 0
+        amax = max(5, a0)
+        for _ in range(4):
+            if f(amax) > 0:
+                a0 = amax
+                amax *= amax
+        amax = brentq(f, a0, amax)
+        if aopt > 0:
+            if f(0) > 0:
+                amin = 0
+            else:
+                amin = brentq(f, 0, aopt)
+        dom = np.linspace(amin, amax, npt)
+        cod = np.empty_like(dom)
+        for i, a in enumerate(dom):
+            cod[i] = self.log_profile_likelihood(a)
+        cod -= llmax
+        return dom, cod
+
+
 # ---------------------------------------------------------------------------
 # a6 (batch): CellsLogLikelihood.__init__/get_flux/get_raw_lightcurve,
 # core.py:1070-1098, 1227-1257, 1295-1336 (profile_background=False)

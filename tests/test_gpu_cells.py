@@ -182,3 +182,75 @@ def test_fit_matches_oracle_on_random_cells(nph, ncell):
             sc = max(1.0, np.abs(np.log1p(-we[off[c]:off[c + 1]])).sum())
             assert abs(alpha[c] - a) <= RTOL * max(1, abs(a)), (c, alpha[c], a)
             assert abs(ts[c] - t) <= RTOL * max(sc, abs(t)), (c, ts[c], t)
+
+
+def test_joint_fit_meets_reference_likelihood(golden):
+    """get_max(profile_background=True): the reference's optimiser (scipy TNC,
+    ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
+    on logL: never lower than the reference's by more than its own margin."""
+    from godot_amd import ops
+    g = golden('profile_bkg.npz')
+    cr, off = _ranges(g, _dev())
+    a, b, L, fl = ops.cell_fit_joint(cr)
+    a, b, L, fl = a.cpu().numpy(), b.cpu().numpy(), L.cpu().numpy(), fl.cpu().numpy()
+    assert not (fl & 0x10).any()
+    assert (L >= g['joint_logl'] - 2e-3).all(), (L - g['joint_logl']).min()
+    assert (a >= 0).all() and (b >= 0).all()
+    # converged: the gradient vanishes, or points outwards on an active bound
+    with np.errstate(all='ignore'):
+        for i in range(len(a)):
+            cl = orc.CellLike(g['we'][off[i]:off[i + 1]], g['exp'][i], g['SonB'][i])
+            _, (nga, ngb) = cl.neg_logl_grad(a[i], b[i])
+            sc = max(1.0, cl.S, cl.B)
+            assert (abs(nga) <= 1e-7 * sc) or (a[i] == 0 and nga >= 0), (i, a[i], nga)
+            assert (abs(ngb) <= 1e-7 * sc) or (b[i] == 0 and ngb >= 0), (i, b[i], ngb)
+            assert abs(L[i] - cl.log_full_likelihood(a[i], b[i])) <= 1e-9 * max(1, abs(L[i]))
+    # distance to the reference's values: informative, bounded by the optimiser tolerance
+    assert np.abs(a - g['joint_ab'][:, 0]).max() < 0.2
+
+
+def test_profile_background_grid_matches_reference(golden):
+    """_get_logpdf_profile centred on a given aopt has no third-party
+    optimiser inside (Brent restated): 1e-9 parity."""
+    from godot_amd import ops
+    g = golden('profile_bkg.npz')
+    cr, off = _ranges(g, _dev())
+    n = len(g['prof_dom'])
+    sub = ops.CellRanges(cr.we, cr.lo[:n].contiguous(), cr.hi[:n].contiguous(), cr.S[:n].contiguous(),
+                         cr.B[:n].contiguous())
+    aopt = torch.from_numpy(g['joint_ab'][:n, 0].copy()).to(cr.device)
+    dom, cod, fl = ops.cell_logpdf_profile(sub, aopt=aopt, dlogl=30, npt=50)
+    dom, cod = dom.cpu().numpy(), cod.cpu().numpy()
+    ok = ~np.isnan(g['prof_dom'][:, 0])
+    assert ok.sum() >= 10
+    sc = _logscale(g, off)[:n, None]
+    # the support limits are roots found to |dx| ~ 2e-12 of a function with slope O(S)
+    _close(dom[ok], g['prof_dom'][ok], rtol=1e-8)
+    _close(cod[ok], g['prof_cod'][ok], scale=np.broadcast_to(sc * 10, cod.shape)[ok], rtol=1e-8)
+
+
+def test_profile_background_lightcurve_close_to_reference(golden):
+    from godot_amd import core
+    g = golden('profile_bkg.npz')
+    d = _dev()
+    n = len(g['prof_lightcurve'])
+    off = np.append(0, np.cumsum(g['counts'])).astype(np.int64)
+    offd = torch.from_numpy(off).to(d)
+    sexp = torch.from_numpy(g['exp']).to(d)
+    bexp = torch.from_numpy(g['exp'] / g['SonB']).to(d)
+    batch = core.CellBatch(torch.from_numpy(g['we']).to(d), torch.from_numpy(g['we']).to(d),
+                           offd[:-1][:n].contiguous(), offd[1:][:n].contiguous(),
+                           torch.from_numpy(g['starts'][:n].copy()).to(d),
+                           torch.from_numpy(g['stops'][:n].copy()).to(d), sexp[:n].contiguous(),
+                           bexp[:n].contiguous())
+    cll = core.CellsLogLikelihood(batch, profile_background=True)
+    lc = cll.get_raw_lightcurve()
+    ref = g['prof_lightcurve']
+    # profile grids start from the joint maximum (optimiser tolerance): loose comparison
+    assert np.abs(cll._dom[:, -1] - g['prof_dom_full'][:, -1]).max() < 0.05 * g['prof_dom_full'][:, -1].max()
+    same_kind = (lc[:, 4] == -1) == (ref[:, 4] == -1)
+    assert same_kind.mean() > 0.9
+    m = same_kind
+    assert np.abs(lc[m, 5] - ref[m, 5]).max() < 0.05 + 1e-3 * np.abs(ref[m, 5]).max()
+    assert np.abs(lc[m, 2] - ref[m, 2]).max() < 0.05
+    assert np.array_equal(lc[:, 0], ref[:, 0]) and np.allclose(lc[:, 1], ref[:, 1], rtol=1e-12)

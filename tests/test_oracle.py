@@ -160,6 +160,14 @@ def test_profile_background_matches_reference(golden):
                 assert c.log_profile_likelihood(al) == g['logl_profile'][i, j]
             ab = g['joint_ab'][i]
             assert c.log_full_likelihood(ab[0], ab[1]) == g['joint_logl'][i]
+            # the joint fit goes through scipy's fmin_tnc with the reference's call sequence
+            assert np.array_equal(np.asarray(c.get_max_profile(), dtype=float), ab)
+        for i in range(len(g['prof_dom'])):
+            if np.isnan(g['prof_dom'][i, 0]):
+                continue
+            dom, cod = clls[i].get_logpdf_profile(aopt=float(g['joint_ab'][i, 0]), dlogl=30, npt=50)
+            assert np.array_equal(dom, g['prof_dom'][i])
+            assert np.array_equal(cod, g['prof_cod'][i])
 
 
 def test_empty_cell_known_answers():

@@ -209,9 +209,25 @@ def main(outdir):
             r = np.asarray(cl.get_max(profile_background=True), dtype=float)
             ab[i] = r
             abll[i] = cl.log_full_likelihood(list(r))
+        # profile-likelihood grids centred on the reference's own joint maxima
+        # (given aopt the routine is deterministic: no third-party optimiser inside)
+        nprof = 16
+        pdom = np.full((nprof, 50), np.nan)
+        pcod = np.full((nprof, 50), np.nan)
+        for i in range(nprof):
+            cl = core.CellLogLikelihood(cells[i])
+            try:
+                pdom[i], pcod[i] = cl.get_logpdf(aopt=float(ab[i, 0]), dlogl=30, npt=50,
+                                                 profile_background=True)
+            except ValueError:
+                pass
+        # and the full profile-background driver (optimiser inside: compared loosely)
+        cllp = core.CellsLogLikelihood(cells[:24], profile_background=True)
+        lcp = cllp.get_raw_lightcurve()
     np.savez_compressed(os.path.join(outdir, 'profile_bkg.npz'),
                         alphas=alphas, beta_max=bm, logl_profile=lp,
-                        joint_ab=ab, joint_logl=abll,
+                        joint_ab=ab, joint_logl=abll, prof_dom=pdom, prof_cod=pcod,
+                        prof_lightcurve=lcp, prof_dom_full=cllp._dom, prof_cod_full=cllp._cod,
                         **{k: o[k] for k in ('starts', 'stops', 'exp', 'SonB',
                                              'counts', 'we')})
     print('profile_bkg: %d cells' % len(cells))
