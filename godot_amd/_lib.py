@@ -74,6 +74,10 @@ SIGNATURES = {
                                                            c_stream]),
     'godot_trigsum_cells': (c_int, [c_f64p] * 4 + [c_i64, c_f64p, c_i64, c_f64, c_f64p, c_stream]),
     'godot_fit_harmonics': (c_int, [c_f64p] * 4 + [c_i64, c_f64, c_f64p, c_i64, c_f64p, c_stream]),
+    'godot_ls_cells': (c_int, [c_f64p, c_f64p, c_i64, c_f64p, c_i64, c_f64p, c_stream]),
+    'godot_orbital_workspace_bytes': (c_size, []),
+    'godot_orbital_modulation_step': (c_int, [c_f64p] * 4 + [c_i64, c_f64, c_f64p, c_f64p, c_ws, c_size,
+                                                             c_stream]),
     'godot_z2m_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'godot_z2m': (c_int, [c_f64p, c_f64p, c_i64, c_f64, c_f64, c_i64, c_i64, c_int, c_f64p, c_f64p,
                           c_ws, c_size, c_stream]),

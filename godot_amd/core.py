@@ -20,7 +20,8 @@ from . import ops
 __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries',
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
            'met2mjd', 'mjd2met', 'infer_met', 'power_spectrum_fft', 'power_spectrum_simple',
-           'power_spectrum_dft', 'fit_harmonics', 'z2m', 'h_test']
+           'power_spectrum_dft', 'fit_harmonics', 'compute_ls', 'get_orbital_modulation', 'z2m',
+           'h_test']
 
 MJDREF = 51910 + 7.428703703703703e-4
 F64 = torch.float64
@@ -716,3 +717,35 @@ def h_test(times, weights, f0, df, nf, mmax=20, j0=0, device=None):
     _, h = ops.z2m(_to_dev(times, dev), _to_dev(weights, dev), f0, df, nf, m=mmax, j0=j0,
                    want_z2=False, want_h=True)
     return h
+
+
+def compute_ls(cll, freqs, unweighted=False):
+    """Lomb-Scargle periodogram of the per-cell flux (reference core.py:2490-2531)."""
+    cr = cll._cr
+    dev = cr.device
+    if unweighted:
+        flux = (cr.hi - cr.lo).to(F64) / cll.exp ** 0.5
+    else:
+        w1, _ = ops.cell_moments(cr.we, cr.lo, cr.hi)
+        flux = w1 - cll.exp
+    flux = flux - flux.mean()
+    flux = flux / flux.std(unbiased=False)
+    out = ops.ls_cells(flux.contiguous(), cll.tmids.contiguous(), _to_dev(freqs, dev))
+    scale = 0.5 * float((flux ** 2).sum().cpu())
+    return _np(out) / scale
+
+
+def get_orbital_modulation(ts, freqs, device=None):
+    """Time-domain sinusoid model at the given frequencies and its powers
+    (reference core.py:2828-2861); the first return value can be passed to
+    power_spectrum_fft as exposure_correction."""
+    dev = device or (ts.weights.device if isinstance(ts.weights, torch.Tensor) else default_device())
+    starts, stops = _ts_dev(ts, 'starts', dev), _ts_dev(ts, 'stops', dev)
+    W, WW, S = _ts_dev(ts, 'weights', dev), _ts_dev(ts, 'weights2', dev), _ts_dev(ts, 'sexp', dev)
+    rvals = torch.ones_like(W)
+    y = ((W - S) / S.mean()).contiguous()
+    pows = np.empty(len(freqs))
+    for i, f in enumerate(freqs):
+        m = _np(ops.orbital_modulation_step(starts, stops, y, WW, float(f), rvals))
+        pows[i] = m[0] ** 2 / m[2] + m[1] ** 2 / m[3]
+    return _np(rvals), pows * float(S.sum().cpu()) ** 2 / S.numel()

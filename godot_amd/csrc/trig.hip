@@ -372,7 +372,119 @@ __global__ __launch_bounds__(256) void fit_harmonics_kernel(const double *w1, co
     }
 }
 
+// compute_ls (core.py:2490-2531): Lomb-Scargle-like sums of a normalised
+// per-cell flux, phases from the 1000-entry table as in power_spectrum_dft.
+__global__ __launch_bounds__(256) void ls_cells_kernel(const double *flux, const double *tmid, int64_t ncell,
+                                                       const double *freqs, double *power)
+{
+#pragma clang fp contract(off)
+    __shared__ double sm[4 * 2];
+    const double f = freqs[blockIdx.x];
+    const double t0 = tmid[0];
+    const double step = 6.283185307179586 / 1000;
+    double v[2] = {0, 0};
+    for (int64_t c = threadIdx.x; c < ncell; c += blockDim.x) {
+        double ph = (tmid[c] - t0) * f;
+        ph = ph - trunc(ph);
+        int k = (int)(ph * 1000);
+        if (k < 0) k += 1000;
+        k = k < 0 ? 0 : (k > 999 ? 999 : k);
+        double ang = k * step;
+        v[0] += cos(ang) * flux[c];
+        v[1] += sin(ang) * flux[c];
+    }
+    block_sums<2>(v, sm);
+    if (threadIdx.x == 0) power[blockIdx.x] = v[0] * v[0] + v[1] * v[1];
+}
+
+// get_orbital_modulation (core.py:2845-2859), one frequency: partial sums of
+// cos*y, sin*y, cos^2*z, sin^2*z over the bins, combined in a fixed order.
+constexpr int OM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void orbital_moments_kernel(const double *starts, const double *stops,
+                                                              const double *y, const double *z, int64_t n,
+                                                              double freq, double *partials)
+{
+    __shared__ double sm[4 * 4];
+    const double t0 = (starts[0] + stops[0]) * 0.5;
+    double v[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x = ((starts[i] + stops[i]) * 0.5 - t0) * freq;
+        double ph = (x - floor(x)) * 6.283185307179586;
+        double sp, cp;
+        sincos(ph, &sp, &cp);
+        v[0] += cp * y[i];
+        v[1] += sp * y[i];
+        v[2] += cp * cp * z[i];
+        v[3] += sp * sp * z[i];
+    }
+    block_sums<4>(v, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) partials[blockIdx.x * 4 + k] = v[k];
+}
+
+__global__ void orbital_finish_kernel(const double *partials, int nblocks, int64_t n, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 4; ++k) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[b * 4 + k];
+        out[k] = s / (double)n;   // np.mean
+    }
+}
+
+__global__ void orbital_update_kernel(const double *starts, const double *stops, int64_t n, double freq,
+                                      const double *means, double *rvals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t0 = (starts[0] + stops[0]) * 0.5;
+    double x = ((starts[i] + stops[i]) * 0.5 - t0) * freq;
+    double ph = (x - floor(x)) * 6.283185307179586;
+    double sp, cp;
+    sincos(ph, &sp, &cp);
+    rvals[i] += 2 * (means[0] * cp + means[1] * sp);
+}
+
 }   // namespace
+
+extern "C" int godot_ls_cells(const double *flux, const double *tmid, int64_t ncell, const double *freqs,
+                              int64_t nfreq, double *power, godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 1 && nfreq >= 0, GODOT_E_INVALID, "godot_ls_cells: bad sizes");
+    GODOT_REQUIRE(nfreq < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_ls_cells: too many frequencies");
+    if (nfreq == 0) return GODOT_OK;
+    GODOT_REQUIRE(flux && tmid && freqs && power, GODOT_E_INVALID, "godot_ls_cells: null argument");
+    hipLaunchKernelGGL(ls_cells_kernel, dim3((unsigned)nfreq), dim3(256), 0, (hipStream_t)stream, flux, tmid,
+                       ncell, freqs, power);
+    GODOT_LAUNCH_CHECK("godot_ls_cells");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_orbital_workspace_bytes(void) { return sizeof(double) * 4 * OM_BLOCKS; }
+
+extern "C" int godot_orbital_modulation_step(const double *starts, const double *stops, const double *y,
+                                             const double *z, int64_t n, double freq, double *means,
+                                             double *rvals, void *workspace, size_t workspace_bytes,
+                                             godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 1, GODOT_E_INVALID, "godot_orbital_modulation_step: n must be positive");
+    GODOT_REQUIRE(starts && stops && y && z && means && rvals, GODOT_E_INVALID,
+                  "godot_orbital_modulation_step: null argument");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_orbital_workspace_bytes(), GODOT_E_WORKSPACE,
+                  "godot_orbital_modulation_step: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int nblocks = (int)(ceil_div(n, 256) < OM_BLOCKS ? ceil_div(n, 256) : OM_BLOCKS);
+    double *partials = (double *)workspace;
+    hipLaunchKernelGGL(orbital_moments_kernel, dim3(nblocks), dim3(256), 0, st, starts, stops, y, z, n, freq,
+                       partials);
+    hipLaunchKernelGGL(orbital_finish_kernel, dim3(1), dim3(64), 0, st, (const double *)partials, nblocks, n,
+                       means);
+    hipLaunchKernelGGL(orbital_update_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, starts, stops,
+                       n, freq, (const double *)means, rvals);
+    GODOT_LAUNCH_CHECK("godot_orbital_modulation_step");
+    return GODOT_OK;
+}
 
 extern "C" size_t godot_z2m_workspace_bytes(int64_t nph, int64_t nf, int m)
 {

@@ -358,3 +358,27 @@ def z2m(t, w, f0, df, nf, m=2, j0=0, want_z2=True, want_h=False, workspace=None)
         _lib.call('godot_z2m', _p(t), _p(w), t.numel(), float(f0), float(df), int(j0), int(nf), int(m),
                   _p(z), _p(h), _p(ws), ws.numel(), _stream(dev))
     return z, h
+
+
+def ls_cells(flux, tmid, freqs):
+    for t, nm in ((flux, 'flux'), (tmid, 'tmid'), (freqs, 'freqs')):
+        _dev_check(t, F64, nm)
+    dev = flux.device
+    out = torch.empty(freqs.numel(), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_ls_cells', _p(flux), _p(tmid), flux.numel(), _p(freqs), freqs.numel(), _p(out),
+                  _stream(dev))
+    return out
+
+
+def orbital_modulation_step(starts, stops, y, z, freq, rvals):
+    """One frequency: returns the 4 means (device) and updates rvals in place."""
+    for t, nm in ((starts, 'starts'), (stops, 'stops'), (y, 'y'), (z, 'z'), (rvals, 'rvals')):
+        _dev_check(t, F64, nm)
+    dev = y.device
+    means = torch.empty(4, dtype=F64, device=dev)
+    ws = _workspace(_lib.lib.godot_orbital_workspace_bytes(), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_orbital_modulation_step', _p(starts), _p(stops), _p(y), _p(z), y.numel(),
+                  float(freq), _p(means), _p(rvals), _p(ws), ws.numel(), _stream(dev))
+    return means

@@ -265,6 +265,24 @@ int godot_fit_harmonics(const double *w1, const double *w2, const double *exp,
                         const double *freqs, int64_t nfreq,
                         double *out /* [nfreq][3] */, godot_stream_t stream);
 
+/* compute_ls (core.py:2490-2531): power[f] = (sum cos*flux)^2 + (sum sin*flux)^2
+ * with the table phases of power_spectrum_dft; flux is the caller's normalised
+ * per-cell series (core.py:2493-2501), the 0.5*sum(flux^2) scale is the caller's. */
+int godot_ls_cells(const double *flux, const double *tmid, int64_t ncell,
+                   const double *freqs, int64_t nfreq, double *power,
+                   godot_stream_t stream);
+
+/* One frequency of get_orbital_modulation (core.py:2845-2859): with
+ * t = (starts+stops)/2, means = {mean(cos*y), mean(sin*y), mean(cos^2*z),
+ * mean(sin^2*z)} (device, 4 doubles) and rvals += 2 (a cos + b sin).
+ * y = (weights - sexp) / mean(sexp), z = weights2 (core.py:2847, 2856).       */
+size_t godot_orbital_workspace_bytes(void);
+int godot_orbital_modulation_step(const double *starts, const double *stops,
+                                  const double *y, const double *z, int64_t n,
+                                  double freq, double *means, double *rvals,
+                                  void *workspace, size_t workspace_bytes,
+                                  godot_stream_t stream);
+
 /* Weighted Z^2_m on the uniform grid f_j = f0 + (j0 + j) df, j = 0..nf-1:
  *   Z2m = 2 / sum(w^2) * sum_{k=1..m} [(sum_i w_i cos 2 pi k f t_i)^2 +
  *                                      (sum_i w_i sin 2 pi k f t_i)^2].

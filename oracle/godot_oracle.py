@@ -739,6 +739,46 @@ def power_spectrum_dft(flat, freqs, unweighted=False):
     return out
 
 
+def compute_ls(flat, counts, freqs, unweighted=False):
+    """core.py:2490-2531."""
+    if unweighted:
+        flux = np.asarray(counts, dtype=float) / flat['exp'] ** 0.5
+    else:
+        off = np.append(0, np.cumsum(counts))
+        flux = np.asarray([np.sum(flat['weights'][off[i]:off[i + 1]])
+                           for i in range(len(counts))]) - flat['exp']
+    flux = flux - flux.mean()
+    flux = flux / flux.std()
+    basis = flat['tmids'] - flat['tmids'][0]
+    grid = np.linspace(0, 2 * np.pi, 1001)[:-1]
+    ctab, stab = np.cos(grid), np.sin(grid)
+    out = np.empty(len(freqs))
+    for i, fr in enumerate(freqs):
+        ph = basis * fr
+        ph = ph - ph.astype(int)
+        k = (ph * 1000).astype(int)
+        out[i] = np.sum(ctab[k] * flux) ** 2 + np.sum(stab[k] * flux) ** 2
+    return out / (0.5 * np.sum(flux ** 2))
+
+
+def get_orbital_modulation(starts, stops, W, WW, sexp, freqs):
+    """core.py:2828-2861."""
+    ti = (starts + stops) * 0.5
+    rvals = np.ones_like(ti)
+    y = (W - sexp) / sexp.mean()
+    pows = np.empty(len(freqs))
+    for i in range(len(freqs)):
+        ph = np.mod((ti - ti[0]) * freqs[i], 1) * (2 * np.pi)
+        cph, sph = np.cos(ph), np.sin(ph)
+        a = np.mean(cph * y)
+        b = np.mean(sph * y)
+        a2 = np.mean(cph ** 2 * WW)
+        b2 = np.mean(sph ** 2 * WW)
+        rvals += 2 * (a * cph + b * sph)
+        pows[i] = (a ** 2 / a2 + b ** 2 / b2)
+    return rvals, pows * sexp.sum() ** 2 / sexp.shape[0]
+
+
 # ---------------------------------------------------------------------------
 # a9 (new API, no reference counterpart -> "parity unpinned"):
 # weighted Z^2_m and H-test on a uniform frequency grid f_j = f0 + j*df.

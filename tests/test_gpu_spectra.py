@@ -74,6 +74,13 @@ def test_power_spectrum_fft_matches_reference(golden):
     for i in range(3):
         ref = g['ps_tweak'][i]
         assert _rel(tw[1 + i], ref, floor=np.abs(ref).max() * 1e-6).all(), i
+    omr, omp = core.get_orbital_modulation(ts, g['om_freqs'])
+    assert np.abs(omr - g['om_rvals']).max() <= 1e-9
+    assert _rel(omp, g['om_pows'], floor=0).all()
+    pc = core.power_spectrum_fft(ts, exposure_correction=omr)
+    for i in range(3):
+        ref = g['ps_corr'][i]
+        assert _rel(pc[1 + i], ref, floor=np.abs(ref).max() * 1e-6).all(), i
     eo = core.power_spectrum_fft(ts, exp_only=True)
     assert _rel(eo[1], g['ps_exp_only'], floor=np.abs(g['ps_exp_only']).max() * 1e-6).all()
 
@@ -112,6 +119,9 @@ def test_trig_sums_match_reference(golden):
     fh = core.fit_harmonics(old, g['freqs'][:16])
     ref = g['harmonics']
     assert _rel(fh, ref, floor=np.abs(ref).max(axis=0, keepdims=True) * 1e-6).all()
+    for unw, key in ((False, 'ls'), (True, 'ls_unweighted')):
+        got = core.compute_ls(old, g['freqs'], unweighted=unw)
+        assert _rel(got, g[key], floor=np.abs(g[key]).max() * 1e-6).all(), key
     c, s, t = core.fit_harmonics(old, float(g['freqs'][3]))
     assert _rel(np.array([c, s, t]), ref[3], floor=np.abs(ref).max(axis=0) * 1e-6).all()
 

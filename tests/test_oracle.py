@@ -116,6 +116,11 @@ def test_timeseries_and_fft_match_reference(golden):
     nz = orc.power_spectrum_fft(*args, no_zero_pad=True)
     assert np.array_equal(nz[0], g['ps_nzp_freqs'])
     assert np.array_equal(np.array(nz[1:]), g['ps_nzp'], equal_nan=True)
+    omr, omp = orc.get_orbital_modulation(b['starts'], b['stops'], b['wsum'], b['w2sum'], b['sexp'],
+                                          g['om_freqs'])
+    assert np.array_equal(omr, g['om_rvals']) and np.array_equal(omp, g['om_pows'])
+    pc = orc.power_spectrum_fft(*args, exposure_correction=omr)
+    assert np.array_equal(np.array(pc[1:]), g['ps_corr'], equal_nan=True)
     f, dl = orc.power_spectrum_simple(b['starts'], b['stops'], b['wsum'],
                                       b['w2sum'], b['sexp'])
     assert np.array_equal(f, g['pss_freqs'])
@@ -133,6 +138,8 @@ def test_trig_sums_match_reference(golden):
                               g['dft_unweighted'], equal_nan=True)
         fh = np.array([orc.fit_harmonics(flat, f) for f in g['freqs'][:16]])
     assert np.array_equal(fh, g['harmonics'], equal_nan=True)
+    assert np.array_equal(orc.compute_ls(flat, g['counts'], g['freqs']), g['ls'])
+    assert np.array_equal(orc.compute_ls(flat, g['counts'], g['freqs'], True), g['ls_unweighted'])
 
 
 def test_exposure_matches_reference(golden):

@@ -245,6 +245,11 @@ def main(outdir):
         o.update(ps_freqs=f, ps_p0=p0, ps_p1=p1, ps_pb=pb)
         amps = core.power_spectrum_fft(ts, get_amps=True)
         o['ps_amps'] = np.array(amps[1:])
+        omf = np.array([1. / 5700., 2.3e-5])
+        omr, omp = core.get_orbital_modulation(ts, omf)
+        o.update(om_freqs=omf, om_rvals=omr, om_pows=omp)
+        f, p0c, p1c, pbc = core.power_spectrum_fft(ts, exposure_correction=omr)
+        o.update(ps_corr=np.array([p0c, p1c, pbc]))
         f, p0t, p1t, pbt = core.power_spectrum_fft(ts, tweak_exp=True)
         o.update(ps_tweak=np.array([p0t, p1t, pbt]))
         f, pe = core.power_spectrum_fft(ts, exp_only=True)
@@ -273,9 +278,11 @@ def main(outdir):
         pd = core.power_spectrum_dft(old, freqs)
         pdu = core.power_spectrum_dft(old, freqs, unweighted=True)
         fh = np.array([core.fit_harmonics(old, f) for f in freqs[:16]])
+        ls = core.compute_ls(old, freqs)
+        lsu = core.compute_ls(old, freqs, unweighted=True)
     np.savez_compressed(
         os.path.join(outdir, 'trig_sums.npz'), freqs=freqs, dft=pd,
-        dft_unweighted=pdu, harmonics=fh,
+        dft_unweighted=pdu, harmonics=fh, ls=ls, ls_unweighted=lsu,
         starts=np.array([c.tstart for c in cells]),
         stops=np.array([c.tstop for c in cells]),
         exp=np.array([c.exp for c in cells]),
