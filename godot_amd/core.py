@@ -638,8 +638,6 @@ def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False,
     l = 2 ** (int(np.log2(nfft)) + 1)
     if no_zero_pad:
         l = W.numel()
-    if l & (l - 1):
-        raise NotImplementedError('transform length %d is not a power of two' % l)
     if l < W.numel():
         raise NotImplementedError('dfgoal gives a transform shorter than the series')
     freqs = np.fft.rfftfreq(l)[:l // 4 + 1] / cells.tsamp()
@@ -659,8 +657,6 @@ def power_spectrum_simple(timeseries, get_amps=False, device=None):
     dev = device or (ts.weights.device if isinstance(ts.weights, torch.Tensor) else default_device())
     W, WW, S = _ts_dev(ts, 'weights', dev), _ts_dev(ts, 'weights2', dev), _ts_dev(ts, 'sexp', dev)
     l = W.numel()
-    if l & (l - 1):
-        raise NotImplementedError('series length %d is not a power of two' % l)
     dl, mom = ops.power_spectrum_simple(W, WW, S, want_moments=get_amps)
     freqs = np.fft.rfftfreq(l)[:(l // 4 + 1)] * (1. / ts.tsamp())
     if get_amps:

@@ -303,23 +303,185 @@ __global__ void ps_simple_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- arbitrary transform lengths: Bluestein's chirp-z form -----------------
+// X[k] = c[k] * sum_n (x[n] c[n]) d[k-n],  c[n] = exp(-i pi n^2 / L), d = conj(c):
+// a circular convolution of length M >= 2L-1 (a power of two) done with the
+// Stockham transform above.  n^2 is reduced modulo 2L in integers, so the
+// chirp phases are exact however long the series is.
+__device__ __forceinline__ cplx chirp(int64_t n, int64_t L, double sign)
+{
+    unsigned __int128 sq = (unsigned __int128)(uint64_t)n * (uint64_t)n;
+    int64_t r = (int64_t)(sq % (unsigned __int128)(2 * L));   // n^2 mod 2L
+    double x = (double)r / (double)(2 * L);                   // cycles in [0, 1)
+    x -= rint(x);
+    return expi_cycles(sign * x);
+}
+
+__global__ void bluestein_kernel_b(int64_t L, int64_t M, cplx *b)
+{
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    cplx v{0.0, 0.0};
+    if (m < L) v = chirp(m, L, +1.0);
+    else if (M - m < L) v = chirp(M - m, L, +1.0);
+    b[m] = v;
+}
+
+__global__ void bluestein_pre_kernel(PackArgs p, int64_t L, int64_t M, cplx *a)
+{
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= M) return;
+    cplx v{0.0, 0.0};
+    if (n < L) {
+        cplx c = chirp(n, L, -1.0);
+        double x = series_at(p, n);
+        v = cplx{x * c.x, x * c.y};
+    }
+    a[n] = v;
+}
+
+// y = conj(A * Bf): its forward transform is M * conj(inverse transform of A * Bf)
+__global__ void bluestein_mul_kernel(const cplx *A, const cplx *Bf, int64_t M, cplx *y)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    cplx t = cmul(A[k], Bf[k]);
+    y[k] = cplx{t.x, -t.y};
+}
+
+__global__ void bluestein_post_kernel(const cplx *Y, int64_t L, int64_t M, int64_t nout, cplx *X)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nout) return;
+    cplx y = Y[k];
+    double inv = 1.0 / (double)M;
+    cplx conv{y.x * inv, -y.y * inv};
+    X[k] = cmul(chirp(k, L, -1.0), conv);
+}
+
+inline int64_t bluestein_M(int64_t L)
+{
+    int64_t M = 1;
+    while (M < 2 * L - 1) M <<= 1;
+    return M;
+}
+
+// workspace: Bf, a, tmp (M complex each)
+inline size_t bluestein_ws(int64_t L) { return 3 * align256(sizeof(cplx) * (size_t)bluestein_M(L)); }
+
+// Transform of `batch` real series of length L into X[s][0..nout-1].
+void bluestein_rfft(const PackArgs *series, int batch, int64_t L, int64_t nout, cplx *X, int64_t xstride,
+                    void *workspace, hipStream_t st)
+{
+    const int64_t M = bluestein_M(L);
+    size_t sz = align256(sizeof(cplx) * (size_t)M);
+    cplx *Bf = (cplx *)workspace;
+    cplx *a = (cplx *)((char *)workspace + sz);
+    cplx *t = (cplx *)((char *)workspace + 2 * sz);
+    unsigned gm = (unsigned)ceil_div(M, 256);
+    hipLaunchKernelGGL(bluestein_kernel_b, dim3(gm), dim3(256), 0, st, L, M, a);
+    cplx *bf = fft_c2c(a, t, M, 1, st);
+    if (bf != Bf) (void)hipMemcpyAsync(Bf, bf, sizeof(cplx) * (size_t)M, hipMemcpyDeviceToDevice, st);
+    for (int sidx = 0; sidx < batch; ++sidx) {
+        hipLaunchKernelGGL(bluestein_pre_kernel, dim3(gm), dim3(256), 0, st, series[sidx], L, M, a);
+        cplx *A = fft_c2c(a, t, M, 1, st);
+        cplx *other = (A == a) ? t : a;
+        hipLaunchKernelGGL(bluestein_mul_kernel, dim3(gm), dim3(256), 0, st, (const cplx *)A, (const cplx *)Bf, M,
+                           other);
+        cplx *Y = fft_c2c(other, A, M, 1, st);
+        hipLaunchKernelGGL(bluestein_post_kernel, dim3((unsigned)ceil_div(nout, 256)), dim3(256), 0, st,
+                           (const cplx *)Y, L, M, nout, X + (int64_t)sidx * xstride);
+    }
+}
+
+// epilogues reading full spectra F[s][0..l/2] (any transform length)
+__global__ void ps_epilogue_full_kernel(const cplx *F, int64_t fstride, int64_t nk, double *p0, double *p1,
+                                        double *pb, double *amps)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    cplx f1 = F[k], f2 = F[fstride + k];
+    double WmS_cos = f1.x, WmS_sin = -f1.y;
+    double WbmB_cos = f2.x, WbmB_sin = -f2.y;
+    double S2 = F[2 * fstride].x, B2 = F[3 * fstride].x, SB = F[4 * fstride].x;
+    double g3 = F[2 * fstride + 2 * k].x, g4 = F[3 * fstride + 2 * k].x, g5 = F[4 * fstride + 2 * k].x;
+    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
+    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
+    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
+    if (k == 0) {
+        WW_sin = 1.;
+        WbWb_sin = 1.;
+    }
+    double a_cos0 = WmS_cos / WW_cos, a_sin0 = WmS_sin / WW_sin;
+    double b_cos0 = WbmB_cos / WbWb_cos, b_sin0 = WbmB_sin / WbWb_sin;
+    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
+    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
+    if (k == 0) den_sin = 0.;
+    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
+    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
+    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
+    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
+    if (amps) {
+        amps[0 * nk + k] = a_cos;
+        amps[1 * nk + k] = a_sin;
+        amps[2 * nk + k] = b_cos;
+        amps[3 * nk + k] = b_sin;
+        amps[4 * nk + k] = a_cos0;
+        amps[5 * nk + k] = a_sin0;
+        amps[6 * nk + k] = b_cos0;
+        amps[7 * nk + k] = b_sin0;
+    }
+    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
+    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
+    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
+    if (p0) p0[k] = dl_nobg;
+    if (p1) p1[k] = dl - dl_null;
+    if (pb) pb[k] = dl_null;
+}
+
+__global__ void ps_simple_epilogue_full_kernel(const cplx *F, int64_t fstride, int64_t nk, double *dlogl,
+                                               double *moments)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    cplx f1 = F[k];
+    double c = f1.x, s = -f1.y;
+    double S2 = F[fstride].x, g = F[fstride + 2 * k].x;
+    double cc = 0.5 * (S2 + g), ss = 0.5 * (S2 - g);
+    if (k == 0) ss = 1.;
+    if (dlogl) dlogl[k] = c * c / cc + s * s / ss;
+    if (moments) {
+        moments[0 * nk + k] = c;
+        moments[1 * nk + k] = s;
+        moments[2 * nk + k] = cc;
+        moments[3 * nk + k] = ss;
+    }
+}
+
 }   // namespace
 
 extern "C" size_t godot_rfft_workspace_bytes(int64_t l)
 {
-    if (l < 4) return 0;
-    return 2 * align256(sizeof(cplx) * (size_t)(l / 2));
+    if (l < 2) return 0;
+    if (is_pow2(l) && l >= 4) return 2 * align256(sizeof(cplx) * (size_t)(l / 2));
+    return bluestein_ws(l);
 }
 
 extern "C" int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out, void *workspace,
                               size_t workspace_bytes, godot_stream_t stream)
 {
-    GODOT_REQUIRE(n >= 0 && l >= 4, GODOT_E_INVALID, "godot_rfft_f64: need n >= 0 and l >= 4");
-    GODOT_REQUIRE(is_pow2(l), GODOT_E_UNSUPPORTED, "godot_rfft_f64: l must be a power of two");
+    GODOT_REQUIRE(n >= 0 && l >= 2, GODOT_E_INVALID, "godot_rfft_f64: need n >= 0 and l >= 2");
+    GODOT_REQUIRE(l < ((int64_t)1 << 40), GODOT_E_UNSUPPORTED, "godot_rfft_f64: l too large");
     GODOT_REQUIRE((x || n == 0) && out, GODOT_E_INVALID, "godot_rfft_f64: null argument");
     GODOT_REQUIRE(workspace && workspace_bytes >= godot_rfft_workspace_bytes(l), GODOT_E_WORKSPACE,
                   "godot_rfft_f64: workspace smaller than godot_rfft_workspace_bytes(l)");
     hipStream_t st = (hipStream_t)stream;
+    if (!(is_pow2(l) && l >= 4)) {
+        PackArgs pa{x, nullptr, n < l ? n : l, 0};
+        bluestein_rfft(&pa, 1, l, l / 2 + 1, (cplx *)out, 0, workspace, st);
+        GODOT_LAUNCH_CHECK("godot_rfft_f64");
+        return GODOT_OK;
+    }
     const int64_t N = l / 2;
     cplx *a = (cplx *)workspace;
     cplx *b = (cplx *)((char *)workspace + align256(sizeof(cplx) * (size_t)N));
@@ -336,6 +498,8 @@ extern "C" int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out
 extern "C" size_t godot_power_spectrum_workspace_bytes(int64_t l)
 {
     if (l < 8) return 0;
+    if (!is_pow2(l))   // five full spectra + the chirp-z buffers
+        return 5 * align256(sizeof(cplx) * (size_t)(l / 2 + 1)) + bluestein_ws(l);
     size_t N1 = (size_t)l / 2, N2 = (size_t)l / 4;
     return 2 * align256(sizeof(cplx) * 2 * N1) + 2 * align256(sizeof(cplx) * 3 * N2);
 }
@@ -346,13 +510,27 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
                                         size_t workspace_bytes, godot_stream_t stream)
 {
     GODOT_REQUIRE(n >= 1 && l >= 8, GODOT_E_INVALID, "godot_power_spectrum_fft: need n >= 1 and l >= 8");
-    GODOT_REQUIRE(is_pow2(l), GODOT_E_UNSUPPORTED,
-                  "godot_power_spectrum_fft: the padded length l must be a power of two");
+    GODOT_REQUIRE(l < ((int64_t)1 << 40), GODOT_E_UNSUPPORTED, "godot_power_spectrum_fft: l too large");
     GODOT_REQUIRE(n <= l, GODOT_E_INVALID, "godot_power_spectrum_fft: n exceeds the padded length");
     GODOT_REQUIRE(W && WW && S && Wb && WbWb && B, GODOT_E_INVALID, "godot_power_spectrum_fft: null series");
     GODOT_REQUIRE(workspace && workspace_bytes >= godot_power_spectrum_workspace_bytes(l), GODOT_E_WORKSPACE,
                   "godot_power_spectrum_fft: workspace smaller than godot_power_spectrum_workspace_bytes(l)");
     hipStream_t st = (hipStream_t)stream;
+    if (!is_pow2(l)) {
+        // any length: five chirp-z transforms, then the epilogue on the full spectra
+        GODOT_REQUIRE(((l / 2) / 2) * 2 <= l / 2 && 2 * (l / 4) <= l / 2, GODOT_E_INVALID,
+                      "godot_power_spectrum_fft: bad length");
+        const int64_t nf = l / 2 + 1, nkk = l / 4 + 1;
+        size_t fsz = align256(sizeof(cplx) * (size_t)nf);
+        cplx *F = (cplx *)workspace;
+        PackArgs ser[5] = {PackArgs{W, S, n, 0}, PackArgs{Wb, B, n, 0}, PackArgs{WW, nullptr, n, 0},
+                           PackArgs{WbWb, nullptr, n, 0}, PackArgs{W, WW, n, 0}};
+        bluestein_rfft(ser, 5, l, nf, F, (int64_t)(fsz / sizeof(cplx)), (char *)workspace + 5 * fsz, st);
+        hipLaunchKernelGGL(ps_epilogue_full_kernel, dim3((unsigned)ceil_div(nkk, 256)), dim3(256), 0, st,
+                           (const cplx *)F, (int64_t)(fsz / sizeof(cplx)), nkk, p0, p1, pb, amps);
+        GODOT_LAUNCH_CHECK("godot_power_spectrum_fft");
+        return GODOT_OK;
+    }
     const int64_t N1 = l / 2, N2 = l / 4, nk = l / 4 + 1;
     char *ws = (char *)workspace;
     size_t sz1 = align256(sizeof(cplx) * 2 * (size_t)N1), sz2 = align256(sizeof(cplx) * 3 * (size_t)N2);
@@ -382,12 +560,21 @@ extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, co
                                            size_t workspace_bytes, godot_stream_t stream)
 {
     GODOT_REQUIRE(n >= 8, GODOT_E_INVALID, "godot_power_spectrum_simple: need n >= 8");
-    GODOT_REQUIRE(is_pow2(n), GODOT_E_UNSUPPORTED,
-                  "godot_power_spectrum_simple: the series length must be a power of two");
     GODOT_REQUIRE(W && WW && S, GODOT_E_INVALID, "godot_power_spectrum_simple: null series");
     GODOT_REQUIRE(workspace && workspace_bytes >= godot_power_spectrum_workspace_bytes(n), GODOT_E_WORKSPACE,
                   "godot_power_spectrum_simple: workspace smaller than godot_power_spectrum_workspace_bytes(n)");
     hipStream_t st = (hipStream_t)stream;
+    if (!is_pow2(n)) {
+        const int64_t nf = n / 2 + 1, nkk = n / 4 + 1;
+        size_t fsz = align256(sizeof(cplx) * (size_t)nf);
+        cplx *F = (cplx *)workspace;
+        PackArgs ser[2] = {PackArgs{W, S, n, 0}, PackArgs{WW, nullptr, n, 0}};
+        bluestein_rfft(ser, 2, n, nf, F, (int64_t)(fsz / sizeof(cplx)), (char *)workspace + 5 * fsz, st);
+        hipLaunchKernelGGL(ps_simple_epilogue_full_kernel, dim3((unsigned)ceil_div(nkk, 256)), dim3(256), 0, st,
+                           (const cplx *)F, (int64_t)(fsz / sizeof(cplx)), nkk, dlogl, moments);
+        GODOT_LAUNCH_CHECK("godot_power_spectrum_simple");
+        return GODOT_OK;
+    }
     const int64_t l = n, N1 = l / 2, N2 = l / 4, nk = l / 4 + 1;
     char *ws = (char *)workspace;
     size_t sz1 = align256(sizeof(cplx) * 2 * (size_t)N1), sz2 = align256(sizeof(cplx) * 3 * (size_t)N2);

@@ -213,9 +213,11 @@ int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n,
 
 /* ---- power spectra: core.py:2598-2782 -------------------------------------- */
 
-/* Real-to-complex forward DFT of x[0..n-1] zero-padded to length l (l a power
- * of two >= 2): out[k] = sum_j x[j] exp(-2 pi i j k / l), k = 0..l/2, stored
- * as interleaved (re, im).  Stands in for numpy.fft.rfft at core.py:2683-2701.
+/* Real-to-complex forward DFT of x[0..n-1] zero-padded (or cut) to length
+ * l >= 2: out[k] = sum_j x[j] exp(-2 pi i j k / l), k = 0..l/2, stored as
+ * interleaved (re, im).  Powers of two run the Stockham transform directly,
+ * other lengths go through a chirp-z (Bluestein) convolution on top of it.
+ * Stands in for numpy.fft.rfft at core.py:2683-2701.
  * workspace: godot_rfft_workspace_bytes(l).                                   */
 size_t godot_rfft_workspace_bytes(int64_t l);
 int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out,
@@ -225,6 +227,8 @@ int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out,
 /* power_spectrum_fft (core.py:2635-2741) from the six per-bin series; the
  * scalar options (tweak_exp, exposure_correction, exp_only, maxN) are applied
  * by the caller to the series before the call.  Outputs have l/4+1 entries.
+ * l may be any length >= 8 (the default padded length is a power of two; the
+ * reference's no_zero_pad=True gives l = n).
  * If amps != NULL it receives the 8 amplitude arrays of get_amps=True
  * (alpha_cos, alpha_sin, beta_cos, beta_sin, alpha_cos0, alpha_sin0,
  * beta_cos0, beta_sin0), [8][l/4+1].
@@ -237,7 +241,7 @@ int godot_power_spectrum_fft(const double *W, const double *WW, const double *S,
                              void *workspace, size_t workspace_bytes,
                              godot_stream_t stream);
 
-/* power_spectrum_simple (core.py:2758-2782): l = n must be a power of two.
+/* power_spectrum_simple (core.py:2758-2782): l = n, any length >= 8.
  * moments (may be NULL) receives (cos, sin, cc, ss), [4][l/4+1].              */
 int godot_power_spectrum_simple(const double *W, const double *WW,
                                 const double *S, int64_t n,

@@ -41,8 +41,8 @@ def test_arguments_are_validated_before_any_device_work():
     with pytest.raises(_lib.GodotError):
         _lib.call('godot_cell_logpdf', 0, 0, 0, 0, 0, 0, 0, 0, 30.0, 5000, 0, 0, 0, 0, 0, 0)
     # unsupported sizes are refused, not approximated
-    rc = lib.godot_rfft_f64(0, 10, 12, 0, 0, 0, 0)
-    assert rc == -4 and 'power of two' in _lib.last_error()
+    rc = lib.godot_rfft_f64(0, 10, 1, 0, 0, 0, 0)
+    assert rc == -1 and 'l >= 2' in _lib.last_error()
     rc = lib.godot_z2m(0, 0, 0, 1.0, 1.0, 0, 10, 21, 0, 0, 0, 0, 0)
     assert rc == -4
     # workspace queries are pure host functions

@@ -23,7 +23,8 @@ def _ts(g):
                                timesys='topocentric', minimum_exposure=0)
 
 
-@pytest.mark.parametrize('l,n', [(4, 3), (8, 8), (16, 5), (32, 32), (64, 33), (256, 256), (1024, 700),
+@pytest.mark.parametrize('l,n', [(2, 2), (3, 3), (5, 4), (6, 6), (7, 9), (12, 12), (1000, 1000),
+                                 (10362, 10362), (99991, 60000), (786432, 786432), (4, 3), (8, 8), (16, 5), (32, 32), (64, 33), (256, 256), (1024, 700),
                                  (4096, 4096), (1 << 13, 5000), (1 << 16, 1 << 16), (1 << 17, 99999),
                                  (1 << 20, 300000)])
 def test_rfft_matches_numpy(l, n):
@@ -81,6 +82,11 @@ def test_power_spectrum_fft_matches_reference(golden):
     for i in range(3):
         ref = g['ps_corr'][i]
         assert _rel(pc[1 + i], ref, floor=np.abs(ref).max() * 1e-6).all(), i
+    nz = core.power_spectrum_fft(ts, no_zero_pad=True)
+    assert np.array_equal(nz[0], g['ps_nzp_freqs'])
+    for i in range(3):
+        ref = g['ps_nzp'][i]
+        assert _rel(nz[1 + i], ref, floor=np.abs(ref).max() * 1e-6).all(), ('no_zero_pad', i)
     eo = core.power_spectrum_fft(ts, exp_only=True)
     assert _rel(eo[1], g['ps_exp_only'], floor=np.abs(g['ps_exp_only']).max() * 1e-6).all()
 
@@ -95,9 +101,11 @@ def test_power_spectrum_simple_matches_reference(golden):
     assert np.array_equal(f, g['pss2_freqs'])
     ref = g['pss2_dlogl']
     assert _rel(dl, ref, floor=np.abs(ref).max() * 1e-6).all()
-    # non power-of-two lengths are refused loudly, not approximated
-    with pytest.raises(NotImplementedError):
-        core.power_spectrum_simple(_ts(g))
+    # any length (chirp-z path)
+    f, dl = core.power_spectrum_simple(_ts(g))
+    assert np.array_equal(f, g['pss_freqs'])
+    ref = g['pss_dlogl']
+    assert _rel(dl, ref, floor=np.abs(ref).max() * 1e-6).all()
 
 
 def test_trig_sums_match_reference(golden):
