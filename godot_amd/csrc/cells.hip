@@ -20,10 +20,12 @@ namespace {
 // where they would hold up the other teams of their wavefront: the team posts
 // (cell, new start) to a queue in LDS and the workgroup then serves the queue
 // with densely packed teams that reload the cell's weights (L2-resident).
-template <int T, int R>
-__global__ __launch_bounds__(256, 4) void cell_fit_kernel(CellArgs p, const double *guess, double guess0,
-                                                       const double *beta, double beta0,
-                                                       double *alpha, double *ts, int32_t *flags)
+// B0: the background level is fixed at its nominal value for every cell
+// (beta = 1, the common case): t2 = 1 is folded at compile time.
+template <int T, int R, bool B0>
+__device__ __forceinline__ void cell_fit_body(const CellArgs &p, const double *guess, double guess0,
+                                              const double *beta, double beta0, double *alpha, double *ts,
+                                              int32_t *flags)
 {
     constexpr int NTEAM = 256 / T;
     __shared__ int q_count[2];
@@ -35,63 +37,89 @@ __global__ __launch_bounds__(256, 4) void cell_fit_kernel(CellArgs p, const doub
     if (threadIdx.x < 2) q_count[threadIdx.x] = 0;
     __syncthreads();
 
-    auto finish = [&](int64_t cell, const CellData<T, R> &cd, double S, double a, int fl) {
-        double t = 0.0;
-        if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, S, a);
-        if (lane == 0) {
-            alpha[cell] = a;
-            if (ts) ts[cell] = (fl & GODOT_F_FAILED) ? qnan() : t;
-            if (flags) flags[cell] = fl;
+    // round 0 serves the workgroup's own cells, rounds 1..3 the restart queue
+    // (the reference recurses at most three deep); one copy of the schedule.
+    for (int depth = 0; depth <= 3; ++depth) {
+        const int qr = (depth + 1) & 1, qw = depth & 1;
+        int64_t cell = cell0 + team;
+        bool active = cell < p.ncell;
+        double g = 0.0, b = 0.0;
+        if (depth > 0) {
+            __syncthreads();
+            const int n = q_count[qr];
+            if (n == 0) break;
+            __syncthreads();
+            if (threadIdx.x == 0) q_count[qw] = 0;
+            __syncthreads();
+            active = team < n;
+            if (active) {
+                cell = cell0 + q_cell[qr][team];
+                g = q_g[qr][team];
+                b = q_b[qr][team];
+            }
+        } else if (active) {
+            g = (guess ? guess[cell] : guess0) - 1;
+            b = B0 ? 0.0 : (beta ? beta[cell] : beta0) - 1;
         }
-    };
-    auto load_cell = [&](int64_t cell, CellData<T, R> &cd, double &S, bool &bad) {
-        int64_t lo = p.lo[cell], hi = p.hi[cell];
-        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
-        S = p.swap ? p.B[cell] : p.S[cell];
-        cd.load(p.we + (bad ? 0 : lo), bad ? 0 : hi - lo, lane, p.swap != 0);
-    };
-    // depth-th pass of cell; posts a restart to queue `qw` or writes the result
-    auto serve = [&](int64_t cell, double g, double b, int depth, int qw) {
-        CellData<T, R> cd;
-        double S;
-        bool bad;
-        load_cell(cell, cd, S, bad);
-        if (bad) {
-            finish(cell, cd, S, qnan(), GODOT_F_FAILED);
-            return;
-        }
-        int fl = depth << 1;
-        double a;
-        bool at_zero;
-        if (fit_attempt(cd, S, g, b, a, at_zero)) {
-            if (at_zero) finish(cell, cd, S, 0.0, fl | GODOT_F_AT_ZERO);
-            else finish(cell, cd, S, a + 1, fl);
-        } else if (depth > 2) {
-            double an = max_numerical(cd, S, fl);
-            finish(cell, cd, S, an, fl);
-        } else if (lane == 0) {
-            int slot = atomicAdd(&q_count[qw], 1);
-            q_cell[qw][slot] = (int)(cell - cell0);
-            q_g[qw][slot] = (a + 1) - 1;
-            q_b[qw][slot] = (b + 1) - 1;
-        }
-    };
+        if (!active) continue;
 
-    {
-        const int64_t cell = cell0 + team;
-        if (cell < p.ncell)
-            serve(cell, (guess ? guess[cell] : guess0) - 1, (beta ? beta[cell] : beta0) - 1, 0, 0);
+        const int64_t lo = p.lo[cell], hi = p.hi[cell];
+        const bool bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        const double S = p.swap ? p.B[cell] : p.S[cell];
+        CellData<T, R> cd;
+        cd.load(p.we + (bad ? 0 : lo), bad ? 0 : hi - lo, lane, p.swap != 0);
+        int fl = depth << 1;
+        double a = qnan();
+        bool at_zero = false, done = true;
+        if (bad) {
+            fl = GODOT_F_FAILED;
+        } else if (fit_attempt_impl<CellData<T, R>, B0>(cd, S, g, b, a, at_zero)) {
+            if (at_zero) {
+                a = 0.0;
+                fl |= GODOT_F_AT_ZERO;
+            } else {
+                a = a + 1;
+            }
+        } else if (depth > 2) {
+            // bracketing fallback: out of line, on a streamed view of the cell
+            StreamCell<T> sc;
+            stream_load(sc, p.we + lo, hi - lo, lane, p.swap != 0);
+            a = max_numerical(sc, S, fl);
+        } else {
+            done = false;
+            if (lane == 0) {
+                int slot = atomicAdd(&q_count[qw], 1);
+                q_cell[qw][slot] = (int)(cell - cell0);
+                q_g[qw][slot] = (a + 1) - 1;
+                q_b[qw][slot] = (b + 1) - 1;
+            }
+        }
+        if (done) {
+            double t = qnan();
+            if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, S, a);
+            if (lane == 0) {
+                alpha[cell] = a;
+                if (ts) ts[cell] = t;
+                if (flags) flags[cell] = fl;
+            }
+        }
     }
-    // restart rounds: depth 1, 2, 3 (the reference recurses at most that deep)
-    for (int depth = 1; depth <= 3; ++depth) {
-        const int qr = (depth - 1) & 1, qw = depth & 1;
-        __syncthreads();
-        const int n = q_count[qr];
-        if (n == 0) break;
-        if (threadIdx.x == 0) q_count[qw] = 0;
-        __syncthreads();
-        if (team < n) serve(cell0 + q_cell[qr][team], q_g[qr][team], q_b[qr][team], depth, qw);
-    }
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256, 4) void cell_fit_b0_kernel(CellArgs p, const double *guess, double guess0,
+                                                             const double *beta, double beta0, double *alpha,
+                                                             double *ts, int32_t *flags)
+{
+    cell_fit_body<T, R, true>(p, guess, guess0, beta, beta0, alpha, ts, flags);
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(256, 4) void cell_fit_bx_kernel(CellArgs p, const double *guess, double guess0,
+                                                             const double *beta, double beta0, double *alpha,
+                                                             double *ts, int32_t *flags)
+{
+    cell_fit_body<T, R, false>(p, guess, guess0, beta, beta0, alpha, ts, flags);
 }
 
 // Sparse cells (a few to a few tens of photons): one LANE per cell, one
@@ -249,7 +277,9 @@ __global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const 
                     a = a + 1;
                 }
             } else if (depth > 2) {
-                a = max_numerical(cd, Sc, fl);
+                StreamCell<QT> sc;
+                stream_load(sc, p.we + l, h - l, tlane, swap);
+                a = max_numerical(sc, Sc, fl);
             } else {
                 if (tlane == 0) {
                     int slot = atomicAdd(&q_count[qw], 1);
@@ -755,9 +785,10 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
         else
             hipLaunchKernelGGL((cell_fit_wave_kernel<32>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
                                alpha, ts, flags);
+    } else if (!beta && beta0 == 1.0) {
+        DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_b0_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts, flags);
     } else {
-        DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts,
-                      flags);
+        DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_bx_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts, flags);
     }
     GODOT_LAUNCH_CHECK("godot_cell_fit");
     return GODOT_OK;

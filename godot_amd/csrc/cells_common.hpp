@@ -25,6 +25,7 @@ struct CellData {
     const double *p;
     int64_t n;
     int lane;
+    int nr;   // photons held in registers (0 when the cell is streamed)
     bool in_regs;
     bool swap;
 
@@ -41,17 +42,35 @@ struct CellData {
         lane = lane_;
         swap = swap_;
         in_regs = n <= (int64_t)T * R;
+        nr = in_regs ? (int)n : 0;
         if (in_regs) {
+            // branch-free: every lane loads R (clamped) addresses back to back and
+            // zeroes what lies beyond the cell
+            const int last = nr > 0 ? nr - 1 : 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                int64_t i = lane + (int64_t)r * T;
-                w[r] = (i < n) ? ld(i) : 0.0;
+            for (int r = 0; r < R; ++r) w[r] = 0.0;
+            if (nr > 0) {
+                // opaque copy: keeps the R slot indices from being hoisted out of an
+                // enclosing loop and held in registers for its whole duration
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = ln + r * T;
+                    const double v = ld(i < last ? i : last);
+                    w[r] = (i < nr) ? v : 0.0;
+                }
             }
         }
     }
 
+    // slot r of this lane's register copy holds a photon of the cell
+    __device__ __forceinline__ bool has(int r) const { return lane + r * T < nr; }
+
     // acc[k] = sum over the cell's photons of what f adds, for k < NS.
-    template <int NS, class F>
+    // ZS: f adds exactly nothing for a zero weight, so the zero padding of the
+    // register copy needs no predication.
+    template <int NS, bool ZS = false, class F>
     __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
     {
 #pragma unroll
@@ -59,7 +78,7 @@ struct CellData {
         if (in_regs) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) f(w[r], acc);
+                if (ZS || has(r)) f(w[r], acc);
         } else {
             for (int64_t i = lane; i < n; i += T) f(ld(i), acc);
         }
@@ -83,7 +102,7 @@ struct CellData {
         if (in_regs) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) {
+                if (has(r)) {
                     double t, g;
                     f(w[r], t, g);
                     pr *= t;
@@ -109,7 +128,7 @@ struct CellData {
 
     // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
     // ratio of the two renormalised products
-    template <class F>
+    template <bool ZS = false, class F>
     __device__ __forceinline__ double logratio(F f) const
     {
         double p1 = 1.0, p2 = 1.0;
@@ -122,7 +141,7 @@ struct CellData {
         if (in_regs) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) {
+                if (ZS || has(r)) {
                     double t1, t2;
                     f(w[r], t1, t2);
                     p1 *= t1;
@@ -153,7 +172,7 @@ struct CellData {
         if (in_regs) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (lane + (int64_t)r * T < n) m = fmax(m, f(w[r]));
+                if (has(r)) m = fmax(m, f(w[r]));
         } else {
             for (int64_t i = lane; i < n; i += T) m = fmax(m, f(ld(i)));
         }
@@ -180,7 +199,7 @@ struct LaneCell {
         return swap ? 1.0 - v : v;
     }
 
-    template <int NS, class F>
+    template <int NS, bool ZS = false, class F>
     __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
     {
 #pragma unroll
@@ -214,7 +233,7 @@ struct LaneCell {
         logs = log(pr) + (double)ex * 0.6931471805599453;
     }
 
-    template <class F>
+    template <bool ZS = false, class F>
     __device__ __forceinline__ double logratio(F f) const
     {
         double p1 = 1.0, p2 = 1.0;
@@ -251,18 +270,36 @@ struct LaneCell {
     }
 };
 
+// A cell read from memory in every pass (no register copy): cheap to hand to
+// out-of-line functions, used on the rare slow paths.
+template <int T>
+using StreamCell = CellData<T, 1>;
+
+template <int T>
+__device__ __forceinline__ void stream_load(StreamCell<T> &cd, const double *base, int64_t n, int lane,
+                                            bool swap)
+{
+    cd.p = base;
+    cd.n = n;
+    cd.lane = lane;
+    cd.swap = swap;
+    cd.in_regs = false;
+    cd.nr = 0;
+    cd.w[0] = 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // get_max with the background level fixed: reference core.py:632-691.
 // g = guess - 1, b = beta - 1 (the reference's zero-based parameters).
 // ---------------------------------------------------------------------------
 
 // f(a) = sum w/(t2 + a w) - S with t2 = 1 + b (1 - w)
-template <class CD>
+template <class CD, bool B0 = false>
 __device__ double score(const CD &cd, double a, double b, double S)
 {
     double acc[1];
-    cd.template sums<1>([=](double w, double (&s)[1]) {
-        double t2 = 1.0 + b * (1.0 - w);
+    cd.template sums<1, true>([=](double w, double (&s)[1]) {
+        double t2 = B0 ? 1.0 : 1.0 + b * (1.0 - w);
         s[0] += w * rcp_fast(t2 + a * w);
     }, acc);
     return acc[0] - S;
@@ -274,20 +311,20 @@ template <class CD>
 __device__ __noinline__ double max_numerical(const CD &cd, double S, int &flags)
 {
     flags |= GODOT_F_BRENT;
-    if (score(cd, -1.0, 0.0, S) < 0) {
+    if (score<CD, true>(cd, -1.0, 0.0, S) < 0) {
         flags |= GODOT_F_AT_ZERO;
         return 0.0;
     }
     double a0 = -1.0, amax = 0.0;
     for (int i = 0; i < 12; ++i) {
-        if (score(cd, amax, 0.0, S) < 0) break;
+        if (score<CD, true>(cd, amax, 0.0, S) < 0) break;
         a0 = amax;
         amax = 2 * amax + 1;
     }
     const double xtol = 1e-3, rtol = 8.881784197001252e-16;
     double xpre = a0, xcur = amax, xblk = 0, fblk = 0, spre = 0, scur = 0;
-    double fpre = score(cd, xpre, 0.0, S);
-    double fcur = score(cd, xcur, 0.0, S);
+    double fpre = score<CD, true>(cd, xpre, 0.0, S);
+    double fcur = score<CD, true>(cd, xcur, 0.0, S);
     if (fpre == 0) return xpre + 1;
     if (fcur == 0) return xcur + 1;
     if (signbit(fpre) == signbit(fcur)) {
@@ -331,7 +368,7 @@ __device__ __noinline__ double max_numerical(const CD &cd, double S, int &flags)
         fpre = fcur;
         if (fabs(scur) > delta) xcur += scur;
         else xcur += (sbis > 0 ? delta : -delta);
-        fcur = score(cd, xcur, 0.0, S);
+        fcur = score<CD, true>(cd, xcur, 0.0, S);
     }
     flags |= GODOT_F_FAILED;
     return qnan();
@@ -359,13 +396,14 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
 {
     double acc[3];
     at_zero = false;
+    if (B0) b = 0.0;
     // t2 = 1 + b (1 - w)
     auto t2of = [=](double w) { return B0 ? 1.0 : 1.0 + b * (1.0 - w); };
     // derivative at alpha = 0 (core.py:639-644) fused with the sums of the
     // first Newton step when that starts from a = 0, b = 0 (w / 1 = w exactly)
     double a = g;
     if (B0 && g == 0.0) {
-        cd.template sums<3>([](double w, double (&s)[3]) {
+        cd.template sums<3, true>([](double w, double (&s)[3]) {
             s[0] += w * rcp_fast1(1.0 - w);
             s[1] += w;
             s[2] += w * w;
@@ -377,12 +415,12 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
         }
         a = a + (acc[1] - S) * rcp_fast(acc[2]);
     } else {
-        if (score(cd, -1.0, b, S) < 0) {
+        if (score<CD, B0>(cd, -1.0, b, S) < 0) {
             at_zero = true;
             a_out = -1.0;
             return true;
         }
-        cd.template sums<2>([=](double w, double (&s)[2]) {
+        cd.template sums<2, true>([=](double w, double (&s)[2]) {
             double r = w * rcp_fast1(fma(g, w, t2of(w)));
             s[0] += r;
             s[1] += r * r;
@@ -392,7 +430,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     // Newton 1 keeps away from zero flux (core.py:653-655)
     if (a < 0 - 1) a = 0.2 - 1;
     auto pass2 = [&](double a_) {
-        cd.template sums<2>([=](double w, double (&s)[2]) {
+        cd.template sums<2, true>([=](double w, double (&s)[2]) {
             double r = w * rcp_fast1(fma(a_, w, t2of(w)));
             s[0] += r;
             s[1] += r * r;
@@ -409,7 +447,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     // Halley (core.py:674-680)
     {
         double a_ = a;
-        cd.template sums<3>([=](double w, double (&s)[3]) {
+        cd.template sums<3, true>([=](double w, double (&s)[3]) {
             double r = w * rcp_fast(fma(a_, w, t2of(w)));
             double r2 = r * r;
             s[0] += r;
@@ -466,7 +504,7 @@ template <class CD>
 __device__ double test_statistic(const CD &cd, double S, double aopt)
 {
     if (S == 0 || aopt == 0) return 0.0;
-    double dl = cd.logratio([=](double w, double &t1, double &t2) {
+    double dl = cd.template logratio<true>([=](double w, double &t1, double &t2) {
         t2 = 1.0 - w;
         t1 = fma(aopt, w, t2);
     });

@@ -11,21 +11,6 @@
 
 namespace {
 
-template <int T>
-using StreamCell = CellData<T, 1>;
-
-template <int T>
-__device__ __forceinline__ void stream_load(StreamCell<T> &cd, const double *base, int64_t n, int lane,
-                                            bool swap)
-{
-    cd.p = base;
-    cd.n = n;
-    cd.lane = lane;
-    cd.swap = swap;
-    cd.in_regs = false;
-    cd.w[0] = 0.0;
-}
-
 // logL(alpha, beta) = sum log(alpha w + beta (1 - w)) - S alpha - B beta
 // (log_full_likelihood, core.py:427-438, in one-based parameters)
 template <int T>
