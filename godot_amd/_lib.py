@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgodot_hip.so')
+# GODOT_HIP_LIBRARY names another build of the same library (e.g. one under test)
+LIB_PATH = os.environ.get('GODOT_HIP_LIBRARY') or os.path.join(_HERE, 'libgodot_hip.so')
 
 c_f64p = ctypes.c_void_p      # device pointers travel as integers
 c_i64p = ctypes.c_void_p

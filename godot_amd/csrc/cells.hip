@@ -122,186 +122,6 @@ __global__ __launch_bounds__(256, 4) void cell_fit_bx_kernel(CellArgs p, const d
     cell_fit_body<T, R, false>(p, guess, guess0, beta, beta0, alpha, ts, flags);
 }
 
-// Sparse cells (a few to a few tens of photons): one LANE per cell, one
-// wavefront (64 cells) per workgroup.  The wavefront reads the photons of its
-// cells with coalesced loads through a small LDS bounce buffer (when the cells
-// are contiguous in memory, which binning produces) and every lane keeps its
-// cell's weights in registers for the whole schedule: no cross-lane
-// reductions, and the per-cell scalar work (Newton updates, clamps, the one
-// logarithm) is shared by 64 cells per instruction.  Cells that ask for a
-// restart, and cells too large for a lane, go through a queue in LDS and are
-// served by 16-lane teams (they read the weights again; L2 holds them).
-// Small LDS and a 128-register cap keep four wavefronts per SIMD resident so
-// that the load latency of one hides behind the arithmetic of the others.
-constexpr int WK_BOUNCE = 1024;   // photons per bounce chunk (8 KB)
-
-template <int RL>
-__global__ __launch_bounds__(64, 4) void cell_fit_wave_kernel(CellArgs p, const double *guess, double guess0,
-                                                              const double *beta, double beta0,
-                                                              double *alpha, double *ts, int32_t *flags)
-{
-    __shared__ double s_b[WK_BOUNCE];
-    __shared__ int q_count[2];
-    __shared__ short q_cell[2][64], q_depth[2][64];
-    __shared__ double q_g[2][64], q_b[2][64];
-
-    const int lane = threadIdx.x;
-    const int64_t cell0 = (int64_t)blockIdx.x * 64;
-    const int64_t cell = cell0 + lane;
-    const bool have = cell < p.ncell;
-    const bool swap = p.swap != 0;
-    if (lane < 2) q_count[lane] = 0;
-
-    int64_t lo = 0, hi = 0;
-    bool bad = false;
-    double S = 0.0;
-    if (have) {
-        lo = p.lo[cell];
-        hi = p.hi[cell];
-        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
-        S = swap ? p.B[cell] : p.S[cell];
-    }
-    const int64_t n64 = (have && !bad) ? hi - lo : 0;
-    const bool big = n64 > 4 * RL;              // served by a team, not by this lane
-    const int n = big ? 0 : (int)n64;
-
-    LaneCell<RL> lc;
-    lc.g = p.we + (bad ? 0 : lo);
-    lc.n = n;
-    lc.swap = swap;
-#pragma unroll
-    for (int r = 0; r < RL; ++r) lc.w[r] = 0.0;
-
-    // are the wavefront's cells one contiguous run of photons?
-    const int64_t next_lo = __shfl_down((long long)lo, 1, WAVE);
-    bool link_ok = !bad;
-    if (have && !bad && lane < 63 && cell + 1 < p.ncell) link_ok = (next_lo == hi);
-    const bool contiguous = __all(link_ok ? 1 : 0);
-    if (contiguous) {
-        const int64_t base = __shfl((long long)lo, 0, WAVE);
-        const int nlast = (int)((p.ncell - cell0) < 64 ? (p.ncell - cell0) : 64) - 1;
-        const int64_t end = __shfl((long long)hi, nlast, WAVE);
-        const int64_t span = end - base;
-        // this cell's first photon in the run (cells beyond 2^31 photons from the base hold none here)
-        const int64_t off64 = lo - base;
-        const int off = (off64 > 0x3fffffff) ? 0x3fffffff : (int)off64;
-        for (int64_t c0 = 0; c0 < span; c0 += WK_BOUNCE) {
-            const int m = (int)((span - c0) < WK_BOUNCE ? (span - c0) : WK_BOUNCE);
-            double v[WK_BOUNCE / 64];
-#pragma unroll
-            for (int u = 0; u < WK_BOUNCE / 64; ++u) {
-                int k = u * 64 + lane;
-                v[u] = (k < m) ? p.we[base + c0 + k] : 0.0;
-            }
-            __syncthreads();                    // the previous chunk has been read
-#pragma unroll
-            for (int u = 0; u < WK_BOUNCE / 64; ++u) s_b[u * 64 + lane] = swap ? 1.0 - v[u] : v[u];
-            __syncthreads();
-            // registers [r_lo, r_hi) of this lane are photons [r_lo + shift, r_hi + shift) of the chunk
-            const int c0i = (c0 > 0x3fffffff) ? 0x3fffffff : (int)c0;
-            const int shift = off - c0i;        // chunk index of the cell's photon 0
-            int r_lo = -shift;
-            r_lo = r_lo < 0 ? 0 : r_lo;
-            int r_hi = m - shift;
-            r_hi = r_hi > n ? n : r_hi;
-            const unsigned width = r_hi > r_lo ? (unsigned)(r_hi - r_lo) : 0u;
-            const double *src = s_b + shift;
-#pragma unroll
-            for (int r = 0; r < RL; ++r)
-                if ((unsigned)(r - r_lo) < width) lc.w[r] = src[r];
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < RL; ++r)
-            if (r < n) lc.w[r] = lc.tail(r);
-    }
-
-    // first pass of the schedule by the lanes
-    if (have) {
-        const double g = (guess ? guess[cell] : guess0) - 1, b = (beta ? beta[cell] : beta0) - 1;
-        if (bad) {
-            alpha[cell] = qnan();
-            if (ts) ts[cell] = qnan();
-            if (flags) flags[cell] = GODOT_F_FAILED;
-        } else if (big) {
-            int slot = atomicAdd(&q_count[0], 1);
-            q_cell[0][slot] = (short)lane;
-            q_depth[0][slot] = 0;
-            q_g[0][slot] = g;
-            q_b[0][slot] = b;
-        } else {
-            double a;
-            bool at_zero;
-            if (fit_attempt(lc, S, g, b, a, at_zero)) {
-                a = at_zero ? 0.0 : a + 1;
-                alpha[cell] = a;
-                if (ts) ts[cell] = test_statistic(lc, S, a);
-                if (flags) flags[cell] = at_zero ? GODOT_F_AT_ZERO : 0;
-            } else {
-                int slot = atomicAdd(&q_count[0], 1);
-                q_cell[0][slot] = (short)lane;
-                q_depth[0][slot] = 1;
-                q_g[0][slot] = (a + 1) - 1;
-                q_b[0][slot] = (b + 1) - 1;
-            }
-        }
-    }
-    // queue rounds: 16-lane teams, four cells at a time
-    constexpr int QT = 16;
-    const int team = lane / QT, tlane = lane % QT;
-    for (int round = 0; round < 5; ++round) {
-        const int qr = round & 1, qw = (round + 1) & 1;
-        __syncthreads();
-        const int nq = q_count[qr];
-        if (nq == 0) break;
-        __syncthreads();
-        if (lane == 0) q_count[qw] = 0;
-        __syncthreads();
-        for (int e = team; e < nq; e += 64 / QT) {
-            const int cl = q_cell[qr][e];
-            const int depth = q_depth[qr][e];
-            const int64_t c = cell0 + cl;
-            const double g = q_g[qr][e], b = q_b[qr][e];
-            const int64_t l = p.lo[c], h = p.hi[c];
-            const double Sc = swap ? p.B[c] : p.S[c];
-            CellData<QT, 4> cd;
-            cd.load(p.we + l, h - l, tlane, swap);
-            int fl = depth << 1;
-            double a, t = 0.0;
-            bool at_zero, done = true;
-            if (fit_attempt(cd, Sc, g, b, a, at_zero)) {
-                if (at_zero) {
-                    a = 0.0;
-                    fl |= GODOT_F_AT_ZERO;
-                } else {
-                    a = a + 1;
-                }
-            } else if (depth > 2) {
-                StreamCell<QT> sc;
-                stream_load(sc, p.we + l, h - l, tlane, swap);
-                a = max_numerical(sc, Sc, fl);
-            } else {
-                if (tlane == 0) {
-                    int slot = atomicAdd(&q_count[qw], 1);
-                    q_cell[qw][slot] = (short)cl;
-                    q_depth[qw][slot] = (short)(depth + 1);
-                    q_g[qw][slot] = (a + 1) - 1;
-                    q_b[qw][slot] = (b + 1) - 1;
-                }
-                done = false;
-            }
-            if (done) {
-                if (ts) t = (fl & GODOT_F_FAILED) ? qnan() : test_statistic(cd, Sc, a);
-                if (tlane == 0) {
-                    alpha[c] = a;
-                    if (ts) ts[c] = t;
-                    if (flags) flags[c] = fl;
-                }
-            }
-        }
-    }
-}
-
 template <int T, int R>
 __global__ __launch_bounds__(256) void cell_loglike_kernel(CellArgs p, const double *alpha, double *out)
 {
@@ -772,19 +592,11 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_fit: swap needs B");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
-    if ((double)nph <= 28.0 * (double)ncell) {
-        // sparse cells: one lane per cell; registers per lane about the mean plus two sigma (Poisson)
-        double mean = (double)nph / (double)ncell;
-        dim3 grid((unsigned)ceil_div(ncell, 64));
-        if (mean <= 4.0)
-            hipLaunchKernelGGL((cell_fit_wave_kernel<8>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
-                               alpha, ts, flags);
-        else if (mean <= 10.0)
-            hipLaunchKernelGGL((cell_fit_wave_kernel<16>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
-                               alpha, ts, flags);
-        else
-            hipLaunchKernelGGL((cell_fit_wave_kernel<32>), grid, dim3(64), 0, st, p, guess, guess0, beta, beta0,
-                               alpha, ts, flags);
+    int gl, gr;
+    if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
+        // sparse cells: groups of one to four lanes per cell (cells_group.hip)
+        godot_detail::fit_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap,
+                                       alpha, ts, flags, st);
     } else if (!beta && beta0 == 1.0) {
         DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_b0_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts, flags);
     } else {

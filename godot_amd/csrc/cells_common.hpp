@@ -4,6 +4,15 @@
 #pragma once
 #include "common.hpp"
 
+// sparse-cell fit kernel (cells_group.hip), launched from godot_cell_fit
+namespace godot_detail {
+bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R);
+void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                      const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
+                      const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
+                      hipStream_t st);
+}
+
 namespace {
 
 
@@ -180,96 +189,6 @@ struct CellData {
     }
 };
 
-// Weights of one cell owned by ONE lane: the first R weights live in
-// registers, zero-padded.  A zero weight adds nothing to any sum of the fit
-// (w/(t2 + a w) = 0) and multiplies the likelihood products by exactly 1, so
-// the register part needs no predication.  Photons beyond R (rare) are read
-// from memory in every pass.  Same interface as CellData; no cross-lane
-// traffic.
-template <int R>
-struct LaneCell {
-    double w[R];
-    const double *g;   // the cell's weights in global memory (for the tail)
-    int n;
-    bool swap;
-
-    __device__ __forceinline__ double tail(int j) const
-    {
-        double v = g[j];
-        return swap ? 1.0 - v : v;
-    }
-
-    template <int NS, bool ZS = false, class F>
-    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
-    {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) f(w[r], acc);
-        for (int j = R; j < n; ++j) f(tail(j), acc);
-    }
-
-    template <class F>
-    __device__ __forceinline__ void logsum(F f, double &logs, double &gsum) const
-    {
-        double pr = 1.0, gs = 0.0;
-        int ex = 0;
-        auto step = [&](double wv, int j) {
-            double t, g;
-            f(wv, t, g);
-            pr *= t;
-            gs += g;
-            if ((j & 7) == 7) {
-                ex += __builtin_amdgcn_frexp_exp(pr);
-                pr = __builtin_amdgcn_frexp_mant(pr);
-            }
-        };
-#pragma unroll
-        for (int r = 0; r < R; ++r) step(w[r], r);
-        for (int j = R; j < n; ++j) step(tail(j), j);
-        ex += __builtin_amdgcn_frexp_exp(pr);
-        pr = __builtin_amdgcn_frexp_mant(pr);
-        gsum = gs;
-        logs = log(pr) + (double)ex * 0.6931471805599453;
-    }
-
-    template <bool ZS = false, class F>
-    __device__ __forceinline__ double logratio(F f) const
-    {
-        double p1 = 1.0, p2 = 1.0;
-        int ex = 0;
-        auto step = [&](double wv, int j) {
-            double t1, t2;
-            f(wv, t1, t2);
-            p1 *= t1;
-            p2 *= t2;
-            if ((j & 7) == 7) {
-                ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
-                p1 = __builtin_amdgcn_frexp_mant(p1);
-                p2 = __builtin_amdgcn_frexp_mant(p2);
-            }
-        };
-#pragma unroll
-        for (int r = 0; r < R; ++r) step(w[r], r);
-        for (int j = R; j < n; ++j) step(tail(j), j);
-        ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
-        p1 = __builtin_amdgcn_frexp_mant(p1);
-        p2 = __builtin_amdgcn_frexp_mant(p2);
-        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
-    }
-
-    template <class F>
-    __device__ __forceinline__ double maxof(F f) const
-    {
-        double m = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (r < n) m = fmax(m, f(w[r]));
-        for (int j = R; j < n; ++j) m = fmax(m, f(tail(j)));
-        return m;
-    }
-};
-
 // A cell read from memory in every pass (no register copy): cheap to hand to
 // out-of-line functions, used on the rare slow paths.
 template <int T>
@@ -374,8 +293,16 @@ __device__ __noinline__ double max_numerical(const CD &cd, double S, int &flags)
     return qnan();
 }
 
-template <class CD, bool B0>
-__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero);
+// log of a product kept as mantissa in [0.5, 1) and binary exponent
+struct LogProd {
+    double m;
+    int e;
+    bool valid;
+};
+
+template <class CD, bool B0, bool CHECK0 = true, bool WANT_L0 = false>
+__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero,
+                                 LogProd *l0 = nullptr);
 
 // One pass of the fixed schedule (core.py:639-680) from the zero-based start
 // values g = guess - 1, b = beta - 1.  Returns true when the result `a` (zero-
@@ -391,8 +318,15 @@ __device__ bool fit_attempt(const CD &cd, double S, double g, double b, double &
 }
 
 
-template <class CD, bool B0>
-__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero)
+// CHECK0 = false: the caller knows that the derivative at alpha = 0 is not
+// negative (a restart: the first pass established it) and the pass that
+// evaluates it is skipped.
+// WANT_L0: the pass that looks at alpha = 0 also forms prod (1 - w_i), the
+// likelihood at alpha = 0 that the test statistic needs, when it runs in its
+// fused form (l0->valid says whether it did).
+template <class CD, bool B0, bool CHECK0, bool WANT_L0>
+__device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero,
+                                 LogProd *l0)
 {
     double acc[3];
     at_zero = false;
@@ -402,12 +336,35 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     // derivative at alpha = 0 (core.py:639-644) fused with the sums of the
     // first Newton step when that starts from a = 0, b = 0 (w / 1 = w exactly)
     double a = g;
+    if constexpr (WANT_L0) l0->valid = false;
     if (B0 && g == 0.0) {
-        cd.template sums<3, true>([](double w, double (&s)[3]) {
-            s[0] += w * rcp_fast1(1.0 - w);
-            s[1] += w;
-            s[2] += w * w;
-        }, acc);
+        if constexpr (WANT_L0) {
+            double pr = 1.0;
+            int ex = 0, k = 0;
+            cd.template sums<3, true>([&](double w, double (&s)[3]) {
+                const double iw = 1.0 - w;
+                s[0] += w * rcp_fast1(iw);
+                s[1] += w;
+                s[2] += w * w;
+                pr *= iw;
+                if ((++k & 7) == 0) {
+                    ex += __builtin_amdgcn_frexp_exp(pr);
+                    pr = __builtin_amdgcn_frexp_mant(pr);
+                }
+            }, acc);
+            ex += __builtin_amdgcn_frexp_exp(pr);
+            pr = __builtin_amdgcn_frexp_mant(pr);
+            cd.reduce_prod(pr, ex);
+            l0->m = pr;
+            l0->e = ex;
+            l0->valid = true;
+        } else {
+            cd.template sums<3, true>([](double w, double (&s)[3]) {
+                s[0] += w * rcp_fast1(1.0 - w);
+                s[1] += w;
+                s[2] += w * w;
+            }, acc);
+        }
         if (acc[0] - S < 0) {
             at_zero = true;
             a_out = -1.0;
@@ -415,7 +372,7 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
         }
         a = a + (acc[1] - S) * rcp_fast(acc[2]);
     } else {
-        if (score<CD, B0>(cd, -1.0, b, S) < 0) {
+        if (CHECK0 && score<CD, B0>(cd, -1.0, b, S) < 0) {
             at_zero = true;
             a_out = -1.0;
             return true;

@@ -1,0 +1,613 @@
+// Fit kernel for sparse cells (a few to a few tens of photons per cell): the
+// shape the ten-minute light curves of the reference produce.
+//
+// A group of L adjacent lanes (L = 1, 2 or 4) owns one cell and keeps its
+// weights in R registers per lane for the whole fixed schedule of
+// CellLogLikelihood.get_max (reference core.py:632-691) and for get_ts
+// (core.py:982-994), so a wavefront fits 64/L cells at once and the per-cell
+// scalar work (Newton updates, clamps, the one logarithm) is shared by that
+// many cells per instruction.  Sums over a cell's photons are combined across
+// its lanes with one or two DPP permutes.
+//
+// A wavefront (= one workgroup) reads the photons of its cells -- one
+// contiguous run of the weights array, as binning produces -- with coalesced
+// loads into LDS; lanes then pick their weights out of it with unconditional
+// reads at fixed offsets.  No barrier anywhere: wavefronts on a CU drift apart
+// and the loads of one overlap the arithmetic of the others.  Photons beyond
+// the L*R register slots of a cell (rare by the choice of L and R) are read
+// from the LDS copy in every pass.
+//
+// Cells whose first pass of the schedule asks for a restart (1 to 10 in 100,
+// more the sparser the cells) are handed to a second kernel through the sign
+// bit of their alpha; it packs them densely and runs the restarts, skipping
+// the pass that only establishes the sign of the derivative at zero.  Cells
+// that end in the bracketing fallback, and cells far larger than the register
+// slots, are fitted one at a time by all 64 lanes.
+
+#include "cells_common.hpp"
+
+namespace {
+
+// Weights of one cell spread over a group of L lanes: lane q of the group
+// holds photons q, q + L, q + 2L, ... in registers, zero-padded.  A zero
+// weight adds nothing to any sum of the fit (w / (t2 + a w) = 0) and
+// multiplies the likelihood products by exactly 1.
+template <int L, int R>
+struct GroupCell {
+    static constexpr int SLOTS = L * R;
+    double w[R];
+    const double *tp;   // photon 0 of the cell for reads beyond the registers (LDS slice or global)
+    int n;              // photons in the cell
+    int q;              // lane inside the group
+    bool tail_swap;     // tp points to raw weights that are to be complemented
+
+    __device__ __forceinline__ double tail(int j) const
+    {
+        double v = tp[j];
+        return tail_swap ? 1.0 - v : v;
+    }
+
+    template <int NS, bool ZS = false, class F>
+    __device__ __forceinline__ void sums(F f, double (&acc)[NS]) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (ZS || r * L + q < n) f(w[r], acc);
+        for (int j = SLOTS + q; j < n; j += L) f(tail(j), acc);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
+    }
+
+    // product over the cell of f(w) as a mantissa in [0.5, 1) and an exponent
+    template <class F>
+    __device__ __forceinline__ void prod(F f, double &m, int &e) const
+    {
+        double pr = 1.0;
+        int ex = 0;
+        auto step = [&](double wv, int k) {
+            pr *= f(wv);
+            if ((k & 7) == 7) {
+                ex += __builtin_amdgcn_frexp_exp(pr);
+                pr = __builtin_amdgcn_frexp_mant(pr);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r) step(w[r], r);
+        int k = R;
+        for (int j = SLOTS + q; j < n; j += L) step(tail(j), k++);
+        ex += __builtin_amdgcn_frexp_exp(pr);
+        pr = __builtin_amdgcn_frexp_mant(pr);
+        reduce_prod(pr, ex);
+        m = pr;
+        e = ex;
+    }
+
+    // combines the lanes' partial products (each a mantissa in [0.5, 1) and an exponent)
+    __device__ __forceinline__ void reduce_prod(double &pr, int &ex) const
+    {
+        pr = team_prod<L>(pr);   // at most four factors in [0.5, 1)
+        ex = team_sum_i32<L>(ex);
+        if (L > 1) {
+            ex += __builtin_amdgcn_frexp_exp(pr);
+            pr = __builtin_amdgcn_frexp_mant(pr);
+        }
+    }
+
+    // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
+    // ratio of two running products (mantissas renormalised every eight factors)
+    template <bool ZS = false, class F>
+    __device__ __forceinline__ double logratio(F f) const
+    {
+        double p1 = 1.0, p2 = 1.0;
+        int ex = 0;
+        auto renorm = [&]() {
+            ex += __builtin_amdgcn_frexp_exp(p1) - __builtin_amdgcn_frexp_exp(p2);
+            p1 = __builtin_amdgcn_frexp_mant(p1);
+            p2 = __builtin_amdgcn_frexp_mant(p2);
+        };
+        auto step = [&](double wv, int k) {
+            double t1, t2;
+            f(wv, t1, t2);
+            p1 *= t1;
+            p2 *= t2;
+            if ((k & 7) == 7) renorm();
+        };
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (ZS || r * L + q < n) step(w[r], r);
+        int k = R;
+        for (int j = SLOTS + q; j < n; j += L) step(tail(j), k++);
+        renorm();
+        p1 = team_prod<L>(p1);   // at most four factors in [0.5, 1)
+        p2 = team_prod<L>(p2);
+        ex = team_sum_i32<L>(ex);
+        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
+    }
+};
+
+// a 64-bit value of one lane as a wave-uniform (scalar) value
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// get_ts (core.py:982-994) when log L(0) = sum log(1 - w_i) is known already:
+// one product of alpha w + (1 - w) = 1 + (alpha - 1) w and one logarithm.
+template <class GC>
+__device__ __forceinline__ double test_statistic_l0(const GC &gc, double S, double aopt, double azb,
+                                                    const LogProd &l0)
+{
+    if (S == 0 || aopt == 0) return 0.0;
+    double m;
+    int e;
+    gc.prod([=](double w) { return fma(azb, w, 1.0); }, m, e);
+    const double dl = log(m * rcp_fast(l0.m)) + (double)(e - l0.e) * 0.6931471805599453;
+    return 2 * (dl - S * aopt);
+}
+
+// every lane of a group reads its photons straight from global memory
+template <int L, int R>
+__device__ __forceinline__ void gather_cell(GroupCell<L, R> &gc, const double *gp, int n, int q, bool swap)
+{
+    gc.tp = gp;
+    gc.n = n;
+    gc.q = q;
+    gc.tail_swap = swap;
+#pragma unroll
+    for (int r = 0; r < R; ++r) gc.w[r] = 0.0;
+    if (n > 0) {
+        const int last = n - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = r * L + q;
+            double v = gp[j < last ? j : last];
+            if (swap) v = 1.0 - v;
+            gc.w[r] = (j < n) ? v : 0.0;
+        }
+    }
+}
+
+// One cell fitted by a whole wavefront that streams its weights (from LDS or
+// from L2) in every pass: the schedule from restart depth `depth` on, with the
+// reference's restart rule (core.py:684-689) and bracketing fallback.
+template <bool B0>
+__device__ __noinline__ void slow_cell_fit(const double *wp, int64_t n, bool swap, double S, double g, double b,
+                                           int depth, bool want_ts, double &a_out, double &t_out, int &fl_out)
+{
+    using SC = StreamCell<64>;
+    SC sc;
+    stream_load(sc, wp, n, (int)(threadIdx.x & 63), swap);
+    int fl = 0;
+    double a = qnan();
+    if (depth > 3) {
+        // the restarts have run out already: straight to the bracketing fallback
+        fl = 3 << 1;
+        a = max_numerical(sc, S, fl);
+    } else for (;; ++depth) {
+        fl = depth << 1;
+        bool at_zero, ok;
+        // a restart knows that the derivative at zero is not negative
+        if (depth == 0) ok = fit_attempt_impl<SC, B0, true>(sc, S, g, b, a, at_zero);
+        else ok = fit_attempt_impl<SC, B0, false>(sc, S, g, b, a, at_zero);
+        if (ok) {
+            if (at_zero) {
+                a = 0.0;
+                fl |= GODOT_F_AT_ZERO;
+            } else {
+                a = a + 1;
+            }
+            break;
+        }
+        if (depth > 2) {
+            a = max_numerical(sc, S, fl);
+            break;
+        }
+        g = (a + 1) - 1;
+        b = (b + 1) - 1;
+    }
+    a_out = a;
+    fl_out = fl;
+    t_out = qnan();
+    if (want_ts && !(fl & GODOT_F_FAILED)) t_out = test_statistic(sc, S, a);
+}
+
+template <int L, int R, bool B0, bool INPLACE>
+__device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const double *guess, double guess0,
+                                                    const double *beta, double beta0, double *alpha,
+                                                    double *ts, int32_t *flags)
+{
+    constexpr int CW = 64 / L;                 // cells per wavefront
+    constexpr int SLOTS = L * R;
+    constexpr int BOUNCE = 52 * R;             // photons in the wavefront's LDS slice
+    constexpr int NLOAD = (BOUNCE + 63) / 64;
+    using GC = GroupCell<L, R>;
+
+    __shared__ double sb[BOUNCE + SLOTS];
+
+    const int lane = threadIdx.x;
+    const int q = lane % L, ci = lane / L;
+    const int64_t cell0 = (int64_t)blockIdx.x * CW;
+    const int64_t cell = cell0 + ci;
+    const bool have = cell < p.ncell;
+    const bool swap = p.swap != 0;
+
+    int64_t lo = 0, hi = 0;
+    bool bad = false;
+    double S = 0.0;
+    if (have) {
+        lo = p.lo[cell];
+        hi = p.hi[cell];
+        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        S = swap ? p.B[cell] : p.S[cell];
+    }
+    const int64_t n64 = (have && !bad) ? hi - lo : 0;
+    const bool big = n64 > 8 * SLOTS;          // fitted by the whole wavefront at the end
+    const int n = big ? 0 : (int)n64;
+
+    // are the wavefront's cells one contiguous run of photons that fits the slice?
+    // (everything wave-uniform is kept in scalar registers)
+    const int64_t left = p.ncell - cell0;
+    const int nvalid = left < CW ? (int)left : CW;      // >= 1 by the grid size
+    const int64_t next_lo = __shfl_down((long long)lo, L, WAVE);
+    bool link_ok = !bad;
+    if (have && !bad && ci + 1 < nvalid) link_ok = (next_lo == hi);
+    const int64_t base = readlane_i64(lo, 0);
+    const int64_t end = readlane_i64(hi, (nvalid - 1) * L);
+    const bool lds_ok = __all(link_ok ? 1 : 0) && (end - base) <= BOUNCE;
+    const int span = lds_ok ? (int)(end - base) : 0;
+
+    GC gc;
+    if (lds_ok) {
+        if (span > 0) {
+            double v[NLOAD];
+            if (base + NLOAD * 64 <= p.nph) {
+                // whole 64-photon rows, the last one possibly past the run (never past the array)
+                const double *vp = p.we + base + lane;
+#pragma unroll
+                for (int u = 0; u < NLOAD; ++u) {
+                    v[u] = 0.0;
+                    if (__builtin_expect(u * 64 < span, 1)) v[u] = vp[u * 64];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NLOAD; ++u) {
+                    const int k = u * 64 + lane;
+                    v[u] = 0.0;
+                    if (u * 64 < span) v[u] = p.we[base + (k < span ? k : span - 1)];
+                }
+            }
+            if (swap) {
+#pragma unroll
+                for (int u = 0; u < NLOAD; ++u) v[u] = 1.0 - v[u];
+            }
+            // rows past the run hold zeros: stored all the same, never read as photons
+#pragma unroll
+            for (int u = 0; u < NLOAD; ++u) {
+                const int k = u * 64 + lane;
+                if (u < NLOAD - 1 || k < BOUNCE) sb[k] = v[u];
+            }
+        }
+        // the slice belongs to this wavefront alone and LDS serves a wavefront's
+        // accesses in order: only the compiler has to be kept from reordering
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int off = have ? (int)(lo - base) : 0;
+        const double *src = sb + off + q;
+        const int nr = (n - q + L - 1) / L;    // register slots of this lane that hold a photon
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double x = src[r * L];       // may lie beyond the cell (never beyond the slice)
+            gc.w[r] = (r < nr) ? x : 0.0;
+        }
+        gc.tp = sb + off;
+        gc.n = n;
+        gc.q = q;
+        gc.tail_swap = false;
+    } else {
+        gather_cell(gc, p.we + (bad ? 0 : lo), n, q, swap);
+    }
+
+    // the schedule, for every cell of the wavefront at once
+    double g = 0.0, b = 0.0;
+    bool restart = false;
+    LogProd l0;
+    l0.valid = false;
+    if (have) {
+        g = (guess ? guess[cell] : guess0) - 1;
+        b = B0 ? 0.0 : (beta ? beta[cell] : beta0) - 1;
+        if (bad) {
+            if (q == 0) {
+                alpha[cell] = qnan();
+                if (ts) ts[cell] = qnan();
+                if (flags) flags[cell] = GODOT_F_FAILED;
+            }
+        } else if (!big) {
+            double a;
+            bool at_zero;
+            if (fit_attempt_impl<GC, B0, true, true>(gc, S, g, b, a, at_zero, &l0)) {
+                const double azb = at_zero ? -1.0 : a;
+                a = at_zero ? 0.0 : a + 1;
+                double t = 0.0;
+                if (ts) t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
+                if (q == 0) {
+                    alpha[cell] = isnan(a) ? qnan() : a;      // sign bit clear: finished
+                    if (ts) ts[cell] = t;
+                    if (flags) flags[cell] = at_zero ? GODOT_F_AT_ZERO : 0;
+                }
+            } else if (INPLACE) {
+                // the reference calls itself again with guess = a + 1 (core.py:684-689)
+                g = (a + 1) - 1;
+                b = (b + 1) - 1;
+                restart = true;
+            } else if (q == 0) {
+                // Restarts are left to the second kernel, which packs them densely:
+                // the new guess (never negative) is handed over with its sign bit set.
+                alpha[cell] = -(a + 1);
+            }
+        }
+    }
+
+    // restarts in place: the same registers go through the schedule again with the
+    // finished lanes masked off (cheaper than a second kernel when about 1 cell in
+    // 100 restarts, dearer when more do)
+    bool brent = false;
+    if (INPLACE && __any(restart ? 1 : 0)) {
+        bool pend = restart;
+        int depth = 1;
+        double a = qnan();
+        while (__any(pend ? 1 : 0)) {
+            if (pend) {
+                bool at_zero;
+                if (fit_attempt_impl<GC, B0, false>(gc, S, g, b, a, at_zero)) {
+                    pend = false;
+                } else if (depth > 2) {
+                    brent = true;
+                    pend = false;
+                } else {
+                    g = (a + 1) - 1;
+                    b = (b + 1) - 1;
+                    ++depth;
+                }
+            }
+        }
+        if (restart && !brent) {
+            const double azb = a;
+            a = a + 1;
+            double t = 0.0;
+            if (ts) t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
+            if (q == 0) {
+                alpha[cell] = isnan(a) ? qnan() : a;
+                if (ts) ts[cell] = t;
+                if (flags) flags[cell] = depth << 1;
+            }
+        }
+    }
+
+    // cells far larger than a group's registers, and cells that end in the bracketing
+    // fallback: one at a time, all 64 lanes on the cell (out of line: keeps the common
+    // path's registers free)
+    unsigned long long todo = __ballot(((big || brent) && q == 0) ? 1 : 0);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t c = cell0 + src / L;
+        const int64_t lo_s = readlane_i64(lo, src), hi_s = readlane_i64(hi, src);
+        const double S_s = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
+        const double g_s = (guess ? guess[c] : guess0) - 1;
+        const double b_s = B0 ? 0.0 : (beta ? beta[c] : beta0) - 1;
+        const int d_s = __builtin_amdgcn_readlane(brent ? 4 : 0, src);
+        // the cell's weights: the LDS copy (already complemented) when there is one
+        const double *wp = lds_ok ? sb + (int)(lo_s - base) : p.we + lo_s;
+        double a_s, t_s;
+        int fl_s;
+        slow_cell_fit<B0>(wp, hi_s - lo_s, lds_ok ? false : swap, S_s, g_s, b_s, d_s, ts != nullptr, a_s, t_s, fl_s);
+        if (lane == 0) {
+            alpha[c] = a_s;
+            if (ts) ts[c] = t_s;
+            if (flags) flags[c] = fl_s;
+        }
+    }
+}
+
+// Second kernel: the restarts.  A wavefront scans GK_SCAN cells for the sign
+// bit that the first kernel left on alpha, packs the cells it finds into a
+// list and fits them like the first kernel does, one group of lanes per cell,
+// with the reference's restart rule (at most three restarts, then the
+// bracketing fallback).  With restarts at a rate of 1 to 10 in 100 cells the
+// lanes of this kernel are well filled, where repeating the schedule in place
+// would run whole wavefronts for one or two cells.
+constexpr int GK_SCAN = 1024;
+
+template <int L, int R, bool B0>
+__device__ __forceinline__ void cell_fit_restart_body(const CellArgs &p, const double *beta, double beta0,
+                                                      double *alpha, double *ts, int32_t *flags)
+{
+    constexpr int CW = 64 / L;
+    using GC = GroupCell<L, R>;
+    __shared__ short s_list[GK_SCAN];
+
+    const int lane = threadIdx.x;
+    const int q = lane % L, ci = lane / L;
+    const int64_t c0 = (int64_t)blockIdx.x * GK_SCAN;
+    const bool swap = p.swap != 0;
+
+    int count = 0;
+#pragma unroll 4
+    for (int k = 0; k < GK_SCAN / 64; ++k) {
+        const int64_t c = c0 + k * 64 + lane;
+        bool f = false;
+        if (c < p.ncell) {
+            const double v = alpha[c];
+            f = (__double_as_longlong(v) < 0) && !isnan(v);
+        }
+        const unsigned long long m = __ballot(f ? 1 : 0);
+        if (f) s_list[count + __popcll(m & ((1ull << lane) - 1))] = (short)(k * 64 + lane);
+        count += __popcll(m);
+    }
+    if (count == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    for (int e0 = 0; e0 < count; e0 += CW) {
+        const int e = e0 + ci;
+        const bool act = e < count;
+        int64_t c = 0, l = 0;
+        double S = 0.0, g = 0.0, b = 0.0;
+        int n = 0;
+        if (act) {
+            c = c0 + s_list[e];
+            l = p.lo[c];
+            n = (int)(p.hi[c] - l);
+            S = swap ? p.B[c] : p.S[c];
+            g = (-alpha[c]) - 1;
+            b = B0 ? 0.0 : (((beta ? beta[c] : beta0) - 1) + 1) - 1;
+        }
+        GC gc;
+        gather_cell(gc, p.we + l, n, q, swap);
+        bool pend = act, brent = false;
+        int depth = 1;
+        double a = qnan();
+        while (__any(pend ? 1 : 0)) {
+            if (pend) {
+                bool at_zero;
+                if (fit_attempt_impl<GC, B0, false>(gc, S, g, b, a, at_zero)) {
+                    pend = false;
+                } else if (depth > 2) {
+                    brent = true;
+                    pend = false;
+                } else {
+                    g = (a + 1) - 1;
+                    b = (b + 1) - 1;
+                    ++depth;
+                }
+            }
+        }
+        if (act && !brent) {
+            a = a + 1;
+            double t = 0.0;
+            if (ts) t = test_statistic(gc, S, a);
+            if (q == 0) {
+                alpha[c] = isnan(a) ? qnan() : a;
+                if (ts) ts[c] = t;
+                if (flags) flags[c] = depth << 1;
+            }
+        }
+        // the bracketing fallback: all 64 lanes on one cell, out of line
+        unsigned long long todo = __ballot((brent && q == 0) ? 1 : 0);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int64_t c_s = readlane_i64(c, src), l_s = readlane_i64(l, src);
+            const int n_s = __builtin_amdgcn_readlane(n, src);
+            const double S_s = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
+            double a_s, t_s;
+            int fl_s;
+            slow_cell_fit<B0>(p.we + l_s, (int64_t)n_s, swap, S_s, 0.0, 0.0, 4, ts != nullptr, a_s, t_s, fl_s);
+            if (lane == 0) {
+                alpha[c_s] = a_s;
+                if (ts) ts[c_s] = t_s;
+                if (flags) flags[c_s] = fl_s;
+            }
+        }
+    }
+}
+
+// register budget: five wavefronts per SIMD (twenty LDS slices per CU)
+template <int L, int R, bool INPLACE>
+__global__ __launch_bounds__(64, 5) void cell_fit_group_b0_kernel(CellArgs p, const double *guess,
+                                                                  double guess0, const double *beta,
+                                                                  double beta0, double *alpha, double *ts,
+                                                                  int32_t *flags)
+{
+    cell_fit_group_body<L, R, true, INPLACE>(p, guess, guess0, beta, beta0, alpha, ts, flags);
+}
+
+template <int L, int R, bool INPLACE>
+__global__ __launch_bounds__(64, 5) void cell_fit_group_bx_kernel(CellArgs p, const double *guess,
+                                                                  double guess0, const double *beta,
+                                                                  double beta0, double *alpha, double *ts,
+                                                                  int32_t *flags)
+{
+    cell_fit_group_body<L, R, false, INPLACE>(p, guess, guess0, beta, beta0, alpha, ts, flags);
+}
+
+template <int L, int R>
+__global__ __launch_bounds__(64, 4) void cell_fit_restart_b0_kernel(CellArgs p, const double *beta, double beta0,
+                                                                    double *alpha, double *ts, int32_t *flags)
+{
+    cell_fit_restart_body<L, R, true>(p, beta, beta0, alpha, ts, flags);
+}
+
+template <int L, int R>
+__global__ __launch_bounds__(64, 4) void cell_fit_restart_bx_kernel(CellArgs p, const double *beta, double beta0,
+                                                                    double *alpha, double *ts, int32_t *flags)
+{
+    cell_fit_restart_body<L, R, false>(p, beta, beta0, alpha, ts, flags);
+}
+
+}   // namespace
+
+namespace godot_detail {
+
+// Group shape for a mean occupancy: L*R register slots hold the mean plus two
+// (Poisson) sigma.  Returns false when the cells are too dense for this kernel.
+bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R)
+{
+    const double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
+    const double need = mean + 2.0 * sqrt(mean);
+    if (need <= 9.0) { L = 1; R = 8; }
+    else if (need <= 17.0) { L = 1; R = 16; }
+    else if (need <= 33.0) { L = 2; R = 16; }
+    else if (need <= 66.0) { L = 4; R = 16; }
+    else return false;
+    return true;
+}
+
+void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                      const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
+                      const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
+                      hipStream_t st)
+{
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    const bool b0 = !beta && beta0 == 1.0;
+    // Sparse cells restart often (1 in 10 at four photons per cell, 1 in 40 at
+    // twelve): their restarts go to the second kernel.  From about sixteen photons
+    // per cell on about 1 in 100 restarts and repeating in place is cheaper.
+    const bool inplace = (double)nph >= 16.0 * (double)ncell;
+    dim3 grid((unsigned)ceil_div(ncell, (int64_t)(64 / L))), block(64);
+    dim3 grid2((unsigned)ceil_div(ncell, (int64_t)GK_SCAN));
+#define GK_LAUNCH_INPLACE(L_, R_)                                                                   \
+    if (L == L_ && R == R_ && inplace) {                                                            \
+        if (b0)                                                                                     \
+            hipLaunchKernelGGL((cell_fit_group_b0_kernel<L_, R_, true>), grid, block, 0, st, p,     \
+                               guess, guess0, beta, beta0, alpha, ts, flags);                       \
+        else                                                                                        \
+            hipLaunchKernelGGL((cell_fit_group_bx_kernel<L_, R_, true>), grid, block, 0, st, p,     \
+                               guess, guess0, beta, beta0, alpha, ts, flags);                       \
+    }
+#define GK_LAUNCH_TWO(L_, R_)                                                                       \
+    if (L == L_ && R == R_ && !inplace) {                                                           \
+        if (b0) {                                                                                   \
+            hipLaunchKernelGGL((cell_fit_group_b0_kernel<L_, R_, false>), grid, block, 0, st, p,    \
+                               guess, guess0, beta, beta0, alpha, ts, flags);                       \
+            hipLaunchKernelGGL((cell_fit_restart_b0_kernel<L_, R_>), grid2, block, 0, st, p, beta,  \
+                               beta0, alpha, ts, flags);                                            \
+        } else {                                                                                    \
+            hipLaunchKernelGGL((cell_fit_group_bx_kernel<L_, R_, false>), grid, block, 0, st, p,    \
+                               guess, guess0, beta, beta0, alpha, ts, flags);                       \
+            hipLaunchKernelGGL((cell_fit_restart_bx_kernel<L_, R_>), grid2, block, 0, st, p, beta,  \
+                               beta0, alpha, ts, flags);                                            \
+        }                                                                                           \
+    }
+    GK_LAUNCH_TWO(1, 8)
+    GK_LAUNCH_TWO(1, 16)
+    GK_LAUNCH_TWO(2, 16)
+    GK_LAUNCH_INPLACE(2, 16)
+    GK_LAUNCH_INPLACE(4, 16)
+#undef GK_LAUNCH_INPLACE
+#undef GK_LAUNCH_TWO
+}
+
+}   // namespace godot_detail

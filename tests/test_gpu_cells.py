@@ -184,6 +184,71 @@ def test_fit_matches_oracle_on_random_cells(nph, ncell):
             assert abs(ts[c] - t) <= RTOL * max(sc, abs(t)), (c, ts[c], t)
 
 
+@pytest.mark.parametrize('mean,variant', [
+    (4, 'plain'), (4, 'guess'), (12.5, 'plain'), (12.5, 'beta'), (12.5, 'scattered'),
+    (22, 'plain'), (22, 'guess'), (22, 'beta'), (22, 'scattered'), (22, 'swap'), (40, 'plain'), (40, 'beta'),
+    (22, 'outliers')])
+def test_fit_sparse_cell_kernels(mean, variant):
+    """Every shape of the sparse-cell kernel (1, 2 or 4 lanes per cell; restarts
+    in place or by the second kernel), with per-cell guesses, a background
+    level other than 1, cells that are not contiguous in memory, complemented
+    weights, and a few cells far larger than the rest."""
+    from godot_amd import ops
+    dev = _dev()
+    ncell = 6000
+    rng = np.random.default_rng(int(mean * 10) + len(variant))
+    cnt = rng.poisson(mean, ncell).astype(np.int64)
+    if variant == 'outliers':
+        cnt[rng.choice(ncell, 12, replace=False)] = rng.integers(100, 3000, 12)
+        cnt[:3] = 0
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    nph = int(off[-1])
+    we = np.clip(rng.beta(0.3, 1.5, nph), 1e-6, 1 - 1e-6)
+    S = np.maximum(cnt * 0.17 * rng.uniform(0.3, 3, ncell), 0.05)
+    B = S * 5
+    lo, hi = off[:-1].copy(), off[1:].copy()
+    order = np.arange(ncell)
+    if variant == 'scattered':
+        order = rng.permutation(ncell)
+    kw = {}
+    guess = np.ones(ncell)
+    beta = 1.0
+    if variant == 'guess':
+        guess = rng.uniform(0.2, 4.0, ncell)
+        kw['guess'] = torch.from_numpy(guess).to(dev)
+    if variant == 'beta':
+        beta = 1.7
+        kw['beta'] = beta
+    wd = torch.from_numpy(we).to(dev)
+    Sd, Bd = torch.from_numpy(S[order]).to(dev), torch.from_numpy(B[order]).to(dev)
+    if variant == 'swap':
+        # complemented weights with S and B exchanged describe the same cells
+        cr = ops.CellRanges(1 - wd, torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev), Bd, Sd)
+        kw['swap'] = True
+    else:
+        cr = ops.CellRanges(wd, torch.from_numpy(lo[order]).to(dev), torch.from_numpy(hi[order]).to(dev), Sd, Bd)
+    alpha, ts, flags = ops.cell_fit(cr, **kw)
+    alpha, ts, flags = alpha.cpu().numpy(), ts.cpu().numpy(), flags.cpu().numpy()
+    assert not (flags & 0x10).any()
+    depth = (flags >> 1) & 3
+    pick = np.unique(np.concatenate([rng.choice(ncell, 300, replace=False), np.flatnonzero(depth > 0)[:150],
+                                     np.flatnonzero(cnt[order] > 64)]))
+    with np.errstate(all='ignore'):
+        for i in pick:
+            c = order[i]
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            a = cl.get_max(guess=guess[i], beta=beta)
+            t = cl.get_ts(a)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            tol = RTOL * (100 if variant == 'swap' else 1)   # 1 - (1 - w) is not w to the last bit
+            assert abs(alpha[i] - a) <= tol * max(1, abs(a)), (i, cnt[c], depth[i], alpha[i], a)
+            assert abs(ts[i] - t) <= tol * max(sc, abs(t)), (i, cnt[c], depth[i], ts[i], t)
+            assert bool(flags[i] & 1) == (a == 0)
+    if variant == 'plain':
+        assert (depth > 0).any()        # the restart path was exercised
+
+
 def test_joint_fit_meets_reference_likelihood(golden):
     """get_max(profile_background=True): the reference's optimiser (scipy TNC,
     ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
