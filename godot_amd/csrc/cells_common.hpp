@@ -95,6 +95,52 @@ struct CellData {
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
     }
 
+    // acc[k] = sum over the cell's photons of what accf(w, d, 1/d, acc) adds, with
+    // d = den(w) > 0.  Both must treat a zero weight as "adds nothing" (den(0) finite):
+    // the zero-padded register copy is used without predication, four at a time.
+    template <int NS, class DEN, class ACC>
+    __device__ __forceinline__ void sums_rcp(DEN den, ACC accf, double (&acc)[NS]) const
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+        if (in_regs) {
+            if constexpr (R % 4 == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r += 4) {
+                    const double d0 = den(w[r]), d1 = den(w[r + 1]), d2 = den(w[r + 2]), d3 = den(w[r + 3]);
+                    double x0, x1, x2, x3;
+                    rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+                    accf(w[r], d0, x0, acc);
+                    accf(w[r + 1], d1, x1, acc);
+                    accf(w[r + 2], d2, x2, acc);
+                    accf(w[r + 3], d3, x3, acc);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double d = den(w[r]);
+                    accf(w[r], d, rcp_fast1(d), acc);
+                }
+            }
+        } else {
+            for (int64_t i = lane; i < n; i += T) {
+                const double wv = ld(i), d = den(wv);
+                accf(wv, d, rcp_fast1(d), acc);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
+    }
+
+    // combines the lanes' partial products (each a mantissa in [0.5, 1) and an exponent)
+    __device__ __forceinline__ void reduce_prod(double &pr, int &ex) const
+    {
+        pr = team_prod<T>(pr);   // factors in [0.5, 1): at worst 2^-64
+        ex = team_sum_i32<T>(ex);
+        ex += __builtin_amdgcn_frexp_exp(pr);
+        pr = __builtin_amdgcn_frexp_mant(pr);
+    }
+
     // sum over the cell of log(t_i) and of g_i, where f(w, t, g) yields the
     // positive t_i and the addend g_i of one photon.  The logarithms are taken
     // of the running product (mantissa renormalised into [0.5, 1) every eight
@@ -217,10 +263,9 @@ template <class CD, bool B0 = false>
 __device__ double score(const CD &cd, double a, double b, double S)
 {
     double acc[1];
-    cd.template sums<1, true>([=](double w, double (&s)[1]) {
-        double t2 = B0 ? 1.0 : 1.0 + b * (1.0 - w);
-        s[0] += w * rcp_fast(t2 + a * w);
-    }, acc);
+    cd.template sums_rcp<1>(
+        [=](double w) { return fma(a, w, B0 ? 1.0 : 1.0 + b * (1.0 - w)); },
+        [](double w, double, double x, double (&s)[1]) { s[0] = fma(w, x, s[0]); }, acc);
     return acc[0] - S;
 }
 
@@ -338,32 +383,29 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     double a = g;
     if constexpr (WANT_L0) l0->valid = false;
     if (B0 && g == 0.0) {
-        if constexpr (WANT_L0) {
-            double pr = 1.0;
-            int ex = 0, k = 0;
-            cd.template sums<3, true>([&](double w, double (&s)[3]) {
-                const double iw = 1.0 - w;
-                s[0] += w * rcp_fast1(iw);
+        double pr = 1.0;
+        int ex = 0, k = 0;
+        cd.template sums_rcp<3>(
+            [](double w) { return 1.0 - w; },
+            [&](double w, double iw, double x, double (&s)[3]) {
+                s[0] = fma(w, x, s[0]);
                 s[1] += w;
-                s[2] += w * w;
-                pr *= iw;
-                if ((++k & 7) == 0) {
-                    ex += __builtin_amdgcn_frexp_exp(pr);
-                    pr = __builtin_amdgcn_frexp_mant(pr);
+                s[2] = fma(w, w, s[2]);
+                if constexpr (WANT_L0) {
+                    pr *= iw;
+                    if ((++k & 7) == 0) {
+                        ex += __builtin_amdgcn_frexp_exp(pr);
+                        pr = __builtin_amdgcn_frexp_mant(pr);
+                    }
                 }
             }, acc);
+        if constexpr (WANT_L0) {
             ex += __builtin_amdgcn_frexp_exp(pr);
             pr = __builtin_amdgcn_frexp_mant(pr);
             cd.reduce_prod(pr, ex);
             l0->m = pr;
             l0->e = ex;
             l0->valid = true;
-        } else {
-            cd.template sums<3, true>([](double w, double (&s)[3]) {
-                s[0] += w * rcp_fast1(1.0 - w);
-                s[1] += w;
-                s[2] += w * w;
-            }, acc);
         }
         if (acc[0] - S < 0) {
             at_zero = true;
@@ -377,21 +419,25 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
             a_out = -1.0;
             return true;
         }
-        cd.template sums<2, true>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast1(fma(g, w, t2of(w)));
-            s[0] += r;
-            s[1] += r * r;
-        }, reinterpret_cast<double (&)[2]>(acc));
+        cd.template sums_rcp<2>(
+            [=](double w) { return fma(g, w, t2of(w)); },
+            [](double w, double, double x, double (&s)[2]) {
+                const double r = w * x;
+                s[0] += r;
+                s[1] = fma(r, r, s[1]);
+            }, reinterpret_cast<double (&)[2]>(acc));
         a = a + (acc[0] - S) * rcp_fast(acc[1]);
     }
     // Newton 1 keeps away from zero flux (core.py:653-655)
     if (a < 0 - 1) a = 0.2 - 1;
     auto pass2 = [&](double a_) {
-        cd.template sums<2, true>([=](double w, double (&s)[2]) {
-            double r = w * rcp_fast1(fma(a_, w, t2of(w)));
-            s[0] += r;
-            s[1] += r * r;
-        }, reinterpret_cast<double (&)[2]>(acc));
+        cd.template sums_rcp<2>(
+            [=](double w) { return fma(a_, w, t2of(w)); },
+            [](double w, double, double x, double (&s)[2]) {
+                const double r = w * x;
+                s[0] += r;
+                s[1] = fma(r, r, s[1]);
+            }, reinterpret_cast<double (&)[2]>(acc));
     };
     // Newton 2 (core.py:658-664)
     pass2(a);
@@ -404,13 +450,15 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
     // Halley (core.py:674-680)
     {
         double a_ = a;
-        cd.template sums<3, true>([=](double w, double (&s)[3]) {
-            double r = w * rcp_fast(fma(a_, w, t2of(w)));
-            double r2 = r * r;
-            s[0] += r;
-            s[1] += r2;
-            s[2] += r2 * r;
-        }, acc);
+        cd.template sums_rcp<3>(
+            [=](double w) { return fma(a_, w, t2of(w)); },
+            [](double w, double, double x, double (&s)[3]) {
+                const double r = w * x;
+                const double r2 = r * r;
+                s[0] += r;
+                s[1] += r2;
+                s[2] = fma(r2, r, s[2]);
+            }, acc);
     }
     double f1 = acc[0] - S, f2 = acc[1], f3 = 2 * acc[2];
     a = pymax(0.0 - 1, a + 2 * f1 * f2 * rcp_fast(2 * f2 * f2 - f1 * f3));

@@ -60,6 +60,32 @@ struct GroupCell {
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
     }
 
+    // acc[k] = sum over the cell's photons of what accf(w, d, 1/d, acc) adds, d = den(w):
+    // the register slots four at a time with one hardware reciprocal
+    template <int NS, class DEN, class ACC>
+    __device__ __forceinline__ void sums_rcp(DEN den, ACC accf, double (&acc)[NS]) const
+    {
+        static_assert(R % 4 == 0, "register slots are taken four at a time");
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+            const double d0 = den(w[r]), d1 = den(w[r + 1]), d2 = den(w[r + 2]), d3 = den(w[r + 3]);
+            double x0, x1, x2, x3;
+            rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+            accf(w[r], d0, x0, acc);
+            accf(w[r + 1], d1, x1, acc);
+            accf(w[r + 2], d2, x2, acc);
+            accf(w[r + 3], d3, x3, acc);
+        }
+        for (int j = SLOTS + q; j < n; j += L) {
+            const double wv = tail(j), d = den(wv);
+            accf(wv, d, rcp_fast1(d), acc);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
+    }
+
     // product over the cell of f(w) as a mantissa in [0.5, 1) and an exponent
     template <class F>
     __device__ __forceinline__ void prod(F f, double &m, int &e) const

@@ -95,6 +95,23 @@ __device__ __forceinline__ double rcp_fast1(double d)
     return fma(x, e, x);
 }
 
+// Reciprocals of four positive numbers from ONE hardware reciprocal: invert the
+// product, then peel the factors off again (nine multiplications).  The
+// hardware reciprocal is a quarter-rate instruction, so this costs about 60 %
+// of four separate rcp_fast1.  Relative error about 2^-46 plus three roundings.
+// The product must stay inside the exponent range: |log10 d_i| < 75.
+__device__ __forceinline__ void rcp4(double d0, double d1, double d2, double d3, double &x0, double &x1,
+                                     double &x2, double &x3)
+{
+    const double ab = d0 * d1, cd = d2 * d3;
+    const double x = rcp_fast1(ab * cd);
+    const double iab = x * cd, icd = x * ab;
+    x0 = iab * d1;
+    x1 = iab * d0;
+    x2 = icd * d3;
+    x3 = icd * d2;
+}
+
 // Python's max(a, b): b only if b > a (so a NaN second argument yields a).
 __device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
 __device__ __forceinline__ double pymin(double a, double b) { return (b < a) ? b : a; }
