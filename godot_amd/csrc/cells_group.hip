@@ -341,37 +341,36 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     bool restart = false;
     LogProd l0;
     l0.valid = false;
+    double o_a = qnan(), o_t = 0.0;           // what this lane's cell puts out
+    int o_fl = 0;
+    bool o_full = false, o_hand = false;      // alpha + TS + flags, or alpha alone (a restart handed on)
     if (have) {
         g = (guess ? guess[cell] : guess0) - 1;
         b = B0 ? 0.0 : (beta ? beta[cell] : beta0) - 1;
         if (bad) {
-            if (q == 0) {
-                alpha[cell] = qnan();
-                if (ts) ts[cell] = qnan();
-                if (flags) flags[cell] = GODOT_F_FAILED;
-            }
+            o_t = qnan();
+            o_fl = GODOT_F_FAILED;
+            o_full = true;
         } else if (!big) {
             double a;
             bool at_zero;
             if (fit_attempt_impl<GC, B0, true, true>(gc, S, g, b, a, at_zero, &l0)) {
                 const double azb = at_zero ? -1.0 : a;
                 a = at_zero ? 0.0 : a + 1;
-                double t = 0.0;
-                if (ts) t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
-                if (q == 0) {
-                    alpha[cell] = isnan(a) ? qnan() : a;      // sign bit clear: finished
-                    if (ts) ts[cell] = t;
-                    if (flags) flags[cell] = at_zero ? GODOT_F_AT_ZERO : 0;
-                }
+                if (ts) o_t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
+                o_a = isnan(a) ? qnan() : a;      // sign bit clear: finished
+                o_fl = at_zero ? GODOT_F_AT_ZERO : 0;
+                o_full = true;
             } else if (INPLACE) {
                 // the reference calls itself again with guess = a + 1 (core.py:684-689)
                 g = (a + 1) - 1;
                 b = (b + 1) - 1;
                 restart = true;
-            } else if (q == 0) {
+            } else {
                 // Restarts are left to the second kernel, which packs them densely:
                 // the new guess (never negative) is handed over with its sign bit set.
-                alpha[cell] = -(a + 1);
+                o_a = -(a + 1);
+                o_hand = true;
             }
         }
     }
@@ -402,13 +401,30 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         if (restart && !brent) {
             const double azb = a;
             a = a + 1;
-            double t = 0.0;
-            if (ts) t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
-            if (q == 0) {
-                alpha[cell] = isnan(a) ? qnan() : a;
-                if (ts) ts[cell] = t;
-                if (flags) flags[cell] = depth << 1;
-            }
+            if (ts) o_t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
+            o_a = isnan(a) ? qnan() : a;
+            o_fl = depth << 1;
+            o_full = true;
+        }
+    }
+
+    // results: the first lanes of the groups hand theirs to lanes 0 .. CW-1, which
+    // store whole rows
+    if (L > 1) {
+        const int from = (lane * L) & 63;
+        o_a = __shfl(o_a, from, WAVE);
+        if (ts) o_t = __shfl(o_t, from, WAVE);
+        o_fl = __shfl(o_fl | (o_full ? 0x100 : 0) | (o_hand ? 0x200 : 0), from, WAVE);
+        o_full = (o_fl & 0x100) != 0;
+        o_hand = (o_fl & 0x200) != 0;
+        o_fl &= 0xff;
+    }
+    if (lane < CW && cell0 + lane < p.ncell) {
+        const int64_t c = cell0 + lane;
+        if (o_full || o_hand) alpha[c] = o_a;
+        if (o_full) {
+            if (ts) ts[c] = o_t;
+            if (flags) flags[c] = o_fl;
         }
     }
 
@@ -540,9 +556,11 @@ __device__ __forceinline__ void cell_fit_restart_body(const CellArgs &p, const d
     }
 }
 
-// register budget: five wavefronts per SIMD (twenty LDS slices per CU)
+// register budget: five wavefronts per SIMD (twenty LDS slices per CU); the
+// variant that repeats restarts in place needs the registers of four per SIMD
+// to stay clear of scratch memory (measured: faster so)
 template <int L, int R, bool INPLACE>
-__global__ __launch_bounds__(64, 5) void cell_fit_group_b0_kernel(CellArgs p, const double *guess,
+__global__ __launch_bounds__(64, INPLACE ? 4 : 5) void cell_fit_group_b0_kernel(CellArgs p, const double *guess,
                                                                   double guess0, const double *beta,
                                                                   double beta0, double *alpha, double *ts,
                                                                   int32_t *flags)
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(64, 5) void cell_fit_group_b0_kernel(CellArgs p, co
 }
 
 template <int L, int R, bool INPLACE>
-__global__ __launch_bounds__(64, 5) void cell_fit_group_bx_kernel(CellArgs p, const double *guess,
+__global__ __launch_bounds__(64, INPLACE ? 4 : 5) void cell_fit_group_bx_kernel(CellArgs p, const double *guess,
                                                                   double guess0, const double *beta,
                                                                   double beta0, double *alpha, double *ts,
                                                                   int32_t *flags)
