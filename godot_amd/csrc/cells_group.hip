@@ -375,36 +375,63 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         }
     }
 
-    // restarts in place: the same registers go through the schedule again with the
-    // finished lanes masked off (cheaper than a second kernel when about 1 cell in
-    // 100 restarts, dearer when more do)
-    bool brent = false;
-    if (INPLACE && __any(restart ? 1 : 0)) {
-        bool pend = restart;
-        int depth = 1;
-        double a = qnan();
-        while (__any(pend ? 1 : 0)) {
-            if (pend) {
-                bool at_zero;
-                if (fit_attempt_impl<GC, B0, false>(gc, S, g, b, a, at_zero)) {
-                    pend = false;
-                } else if (depth > 2) {
-                    brent = true;
-                    pend = false;
-                } else {
-                    g = (a + 1) - 1;
-                    b = (b + 1) - 1;
-                    ++depth;
+    // Restarts in place (about 1 cell in 100 here, one or two per wavefront that has
+    // any): four at a time by teams of 16 lanes, which take the cell's weights from
+    // the LDS copy -- a fraction of the instructions that sending the whole wavefront
+    // through the schedule again for one cell would cost.
+    if (INPLACE) {
+        constexpr int QT = 16;
+        using TC = CellData<QT, 4>;
+        const int team = lane / QT, tl = lane % QT;
+        unsigned long long todo = __ballot((restart && q == 0) ? 1 : 0);
+        while (todo) {
+            // the team's cell: the team-th of the next four restarts
+            int src = -1;
+#pragma unroll
+            for (int t = 0; t < 64 / QT; ++t) {
+                if (todo) {
+                    const int sl = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    if (team == t) src = sl;
                 }
             }
-        }
-        if (restart && !brent) {
-            const double azb = a;
-            a = a + 1;
-            if (ts) o_t = l0.valid ? test_statistic_l0(gc, S, a, azb, l0) : test_statistic(gc, S, a);
-            o_a = isnan(a) ? qnan() : a;
-            o_fl = depth << 1;
-            o_full = true;
+            const int from = src < 0 ? lane : src;
+            const int64_t lo_s = __shfl((long long)lo, from, WAVE);
+            const int n_s = __shfl(n, from, WAVE);
+            const double S_s = __shfl(S, from, WAVE);
+            double g_s = __shfl(g, from, WAVE), b_s = __shfl(b, from, WAVE);
+            if (src >= 0) {
+                const int64_t c = cell0 + src / L;
+                TC cd;
+                if (lds_ok) cd.load(sb + (int)(lo_s - base), n_s, tl, false);
+                else cd.load(p.we + lo_s, n_s, tl, swap);
+                int depth = 1, fl = 0;
+                double a = qnan();
+                for (;; ++depth) {
+                    bool at_zero;
+                    fl = depth << 1;
+                    if (fit_attempt_impl<TC, B0, false>(cd, S_s, g_s, b_s, a, at_zero)) {
+                        a = a + 1;
+                        break;
+                    }
+                    if (depth > 2) {
+                        // bracketing fallback: out of line, on a streamed view of the cell
+                        StreamCell<QT> sc;
+                        stream_load(sc, p.we + lo_s, (int64_t)n_s, tl, swap);
+                        a = max_numerical(sc, S_s, fl);
+                        break;
+                    }
+                    g_s = (a + 1) - 1;
+                    b_s = (b_s + 1) - 1;
+                }
+                double t = qnan();
+                if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, S_s, a);
+                if (tl == 0) {
+                    alpha[c] = isnan(a) ? qnan() : a;
+                    if (ts) ts[c] = t;
+                    if (flags) flags[c] = fl;
+                }
+            }
         }
     }
 
@@ -428,19 +455,18 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         }
     }
 
-    // cells far larger than a group's registers, and cells that end in the bracketing
-    // fallback: one at a time, all 64 lanes on the cell (out of line: keeps the common
-    // path's registers free)
-    unsigned long long todo = __ballot(((big || brent) && q == 0) ? 1 : 0);
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
+    // cells far larger than a group's registers: one at a time, all 64 lanes on the
+    // cell (out of line: keeps the common path's registers free)
+    unsigned long long bigs = __ballot((big && q == 0) ? 1 : 0);
+    while (bigs) {
+        const int src = __builtin_ctzll(bigs);
+        bigs &= bigs - 1;
         const int64_t c = cell0 + src / L;
         const int64_t lo_s = readlane_i64(lo, src), hi_s = readlane_i64(hi, src);
         const double S_s = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
         const double g_s = (guess ? guess[c] : guess0) - 1;
         const double b_s = B0 ? 0.0 : (beta ? beta[c] : beta0) - 1;
-        const int d_s = __builtin_amdgcn_readlane(brent ? 4 : 0, src);
+        const int d_s = 0;
         // the cell's weights: the LDS copy (already complemented) when there is one
         const double *wp = lds_ok ? sb + (int)(lo_s - base) : p.we + lo_s;
         double a_s, t_s;
