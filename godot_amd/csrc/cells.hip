@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
             p0 *= p1;
             ex += __builtin_amdgcn_frexp_exp(p0);
             p0 = __builtin_amdgcn_frexp_mant(p0);
-            s_cod[k] = (log(p0) + (double)ex * 0.6931471805599453) - s_S[c] * a;
+            s_cod[k] = log_mant(p0, ex) - s_S[c] * a;
         }
         __syncthreads();
         // phase 3: agreement of the grid maximum with llmax (core.py:923-929)

@@ -178,7 +178,7 @@ struct CellData {
         pr = team_prod<T>(pr);   // factors in [0.5, 1): at worst 2^-64
         ex = team_sum_i32<T>(ex);
         gsum = team_sum<T>(gs);
-        logs = log(pr) + (double)ex * 0.6931471805599453;
+        logs = log_scaled(pr, ex);
     }
 
     // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
@@ -217,7 +217,7 @@ struct CellData {
         p1 = team_prod<T>(p1);
         p2 = team_prod<T>(p2);
         ex = team_sum_i32<T>(ex);
-        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
+        return log_scaled(p1 * rcp_fast(p2), ex);
     }
 
     template <class F>

@@ -149,7 +149,7 @@ struct GroupCell {
         p1 = team_prod<L>(p1);   // at most four factors in [0.5, 1)
         p2 = team_prod<L>(p2);
         ex = team_sum_i32<L>(ex);
-        return log(p1 * rcp_fast(p2)) + (double)ex * 0.6931471805599453;
+        return log_scaled(p1 * rcp_fast(p2), ex);
     }
 };
 
@@ -171,7 +171,7 @@ __device__ __forceinline__ double test_statistic_l0(const GC &gc, double S, doub
     double m;
     int e;
     gc.prod([=](double w) { return fma(azb, w, 1.0); }, m, e);
-    const double dl = log(m * rcp_fast(l0.m)) + (double)(e - l0.e) * 0.6931471805599453;
+    const double dl = log_scaled(m * rcp_fast(l0.m), e - l0.e);
     return 2 * (dl - S * aopt);
 }
 

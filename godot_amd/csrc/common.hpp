@@ -95,6 +95,38 @@ __device__ __forceinline__ double rcp_fast1(double d)
     return fma(x, e, x);
 }
 
+// log(m * 2^e) for a mantissa m in [0.5, 1) as frexp delivers it (what the running
+// products of the likelihood are kept as); a zero product gives -inf, NaN gives NaN.
+// m is moved to [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), and
+// log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^16/17); |s| <= 0.172 leaves a truncation
+// error below 1e-15 relative.  About a third of the instructions of the library log.
+__device__ __forceinline__ double log_mant(double m, int e)
+{
+    if (!(m > 0)) return m == 0 ? -INFINITY : __longlong_as_double(0x7ff8000000000000LL);
+    const bool low = m < 0.7071067811865476;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;                   // exact
+    const double s = f * rcp_fast(2.0 + f);
+    const double z = s * s;
+    double q = 1.0 / 17.0;
+    q = fma(q, z, 1.0 / 15.0);
+    q = fma(q, z, 1.0 / 13.0);
+    q = fma(q, z, 1.0 / 11.0);
+    q = fma(q, z, 1.0 / 9.0);
+    q = fma(q, z, 1.0 / 7.0);
+    q = fma(q, z, 1.0 / 5.0);
+    q = fma(q, z, 1.0 / 3.0);
+    const double s2 = s + s;
+    return fma((double)e, 0.6931471805599453, fma(s2 * z, q, s2));
+}
+
+// log(x * 2^e) for a positive, normal x
+__device__ __forceinline__ double log_scaled(double x, int e)
+{
+    return log_mant(__builtin_amdgcn_frexp_mant(x), e + __builtin_amdgcn_frexp_exp(x));
+}
+
 // Reciprocals of four positive numbers from ONE hardware reciprocal: invert the
 // product, then peel the factors off again (nine multiplications).  The
 // hardware reciprocal is a quarter-rate instruction, so this costs about 60 %
