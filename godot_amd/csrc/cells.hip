@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void cell_beta_kernel(CellArgs p, const double
 constexpr int LP_CH = 16;
 constexpr int LP_T = 16;
 constexpr int LP_R = 4;
+constexpr int LP_PPL = 4;    // grid points per lane in the evaluation phase
 constexpr int LP_MAX_RECENTRE = 50;
 
 struct Support {
@@ -284,9 +285,13 @@ __device__ __forceinline__ double grid_point(double amin, double amax, double st
     return prod + amin;
 }
 
-__global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const double *aopt_in, double dlogl,
-                                                          int npt, int include_zero, double *dom,
-                                                          double *cod, int32_t *flags)
+// wts = p.we once more, as a parameter that promises not to alias the outputs:
+// that is what lets the compiler read weights at wave-uniform addresses with
+// scalar loads.
+__global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const double *__restrict__ wts,
+                                                          const double *__restrict__ aopt_in, double dlogl,
+                                                          int npt, int include_zero, double *__restrict__ dom,
+                                                          double *__restrict__ cod, int32_t *__restrict__ flags)
 {
     extern __shared__ double s_cod[];   // [LP_CH][npt]
     __shared__ double s_amin[LP_CH], s_amax[LP_CH], s_step[LP_CH], s_llmax[LP_CH], s_S[LP_CH],
@@ -354,39 +359,73 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
             }
         }
         __syncthreads();
-        // phase 2: grid evaluation, (cell, point) pairs over all threads
-        for (int k = tid; k < LP_CH * npt; k += blockDim.x) {
-            int c = k / npt, i = k - c * npt;
-            if (s_state[c] != 0) continue;
-            double a = grid_point(s_amin[c], s_amax[c], s_step[c], i, npt);
-            const double *w = p.we + s_lo[c];
-            int64_t n = s_n[c];
-            // log of the product of the terms (see CellData::logsum): two
-            // independent product chains, renormalised every eight factors
-            double p0 = 1.0, p1 = 1.0;
-            int ex = 0;
-            int64_t j = 0;
-            for (; j + 8 <= n; j += 8) {
+        // phase 2: grid evaluation.  A wavefront takes one cell at a time, so the
+        // cell's weights are wave-uniform (scalar loads, no vector-memory traffic)
+        // and a lane carries LP_PPL grid points as independent product chains.
+        // alpha w + (1 - w) is formed as 1 + (alpha - 1) w; on complemented
+        // weights that is alpha - (alpha - 1) w.
+        {
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int c = wv; c < LP_CH; c += 4) {
+                if (s_state[c] != 0) continue;
+                const double amin_c = s_amin[c], amax_c = s_amax[c], step_c = s_step[c], S_c = s_S[c];
+                const int64_t lo_c = __builtin_amdgcn_readfirstlane((int)s_lo[c]) |
+                                     ((int64_t)__builtin_amdgcn_readfirstlane((int)(s_lo[c] >> 32)) << 32);
+                const int n_c = __builtin_amdgcn_readfirstlane((int)s_n[c]);
+                const double *w = wts + lo_c;
+                for (int i0 = 0; i0 < npt; i0 += 64 * LP_PPL) {
+                    double av[LP_PPL], am1[LP_PPL], pr[LP_PPL];
+                    int ex[LP_PPL];
 #pragma unroll
-                for (int q = 0; q < 8; q += 2) {
-                    double w0 = w[j + q], w1 = w[j + q + 1];
-                    if (swap) { w0 = 1.0 - w0; w1 = 1.0 - w1; }
-                    p0 *= fma(w0, a, 1.0 - w0);
-                    p1 *= fma(w1, a, 1.0 - w1);
+                    for (int u = 0; u < LP_PPL; ++u) {
+                        int i = i0 + u * 64 + ln;
+                        i = i < npt ? i : npt - 1;
+                        av[u] = grid_point(amin_c, amax_c, step_c, i, npt);
+                        am1[u] = av[u] - 1.0;
+                        pr[u] = 1.0;
+                        ex[u] = 0;
+                    }
+                    int j = 0;
+                    if (!swap) {
+                        for (; j + 8 <= n_c; j += 8) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const double wj = w[j + k];
+#pragma unroll
+                                for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
+                            }
+#pragma unroll
+                            for (int u = 0; u < LP_PPL; ++u) {
+                                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                            }
+                        }
+                        for (; j < n_c; ++j) {
+                            const double wj = w[j];
+#pragma unroll
+                            for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
+                        }
+                    } else {
+                        for (; j < n_c; ++j) {
+                            const double wj = w[j];
+#pragma unroll
+                            for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(-am1[u], wj, av[u]);
+                            if ((j & 7) == 7) {
+#pragma unroll
+                                for (int u = 0; u < LP_PPL; ++u) {
+                                    ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                                    pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < LP_PPL; ++u) {
+                        const int i = i0 + u * 64 + ln;
+                        if (i < npt) s_cod[c * npt + i] = log_scaled(pr[u], ex[u]) - S_c * av[u];
+                    }
                 }
-                ex += __builtin_amdgcn_frexp_exp(p0) + __builtin_amdgcn_frexp_exp(p1);
-                p0 = __builtin_amdgcn_frexp_mant(p0);
-                p1 = __builtin_amdgcn_frexp_mant(p1);
             }
-            for (; j < n; ++j) {
-                double w0 = w[j];
-                if (swap) w0 = 1.0 - w0;
-                p0 *= fma(w0, a, 1.0 - w0);
-            }
-            p0 *= p1;
-            ex += __builtin_amdgcn_frexp_exp(p0);
-            p0 = __builtin_amdgcn_frexp_mant(p0);
-            s_cod[k] = log_mant(p0, ex) - s_S[c] * a;
         }
         __syncthreads();
         // phase 3: agreement of the grid maximum with llmax (core.py:923-929)
@@ -670,7 +709,7 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     size_t smem = (size_t)LP_CH * npt * sizeof(double);
     dim3 grid((unsigned)ceil_div(ncell, LP_CH));
-    hipLaunchKernelGGL(cell_logpdf_kernel, grid, dim3(256), smem, st, p, aopt, dlogl, npt,
+    hipLaunchKernelGGL(cell_logpdf_kernel, grid, dim3(256), smem, st, p, we, aopt, dlogl, npt,
                        include_zero, dom, cod, flags);
     GODOT_LAUNCH_CHECK("godot_cell_logpdf");
     return GODOT_OK;
