@@ -209,82 +209,6 @@ constexpr int LP_R = 4;
 constexpr int LP_PPL = 4;    // grid points per lane in the evaluation phase
 constexpr int LP_MAX_RECENTRE = 50;
 
-struct Support {
-    double amin, amax, llmax;
-};
-
-template <class CD>
-__device__ Support support_search(const CD &cd, double S, double aopt, double dlogl,
-                                  bool include_zero)
-{
-    Support r;
-    double amin = 0.0, amax, llmax;
-    double acc[2];
-    // Newton step on logL(a) - llmax + dlogl = 0
-    auto f0f1 = [&](double a) {
-        cd.logsum([=](double w, double &t, double &g) {
-            t = fma(a, w, 1.0 - w);
-            g = w * rcp_fast(t);
-        }, acc[0], acc[1]);
-    };
-    if (aopt == 0) {   // core.py:869-880
-        cd.logsum([](double w, double &t, double &g) {
-            t = 1.0 - w;
-            g = w * rcp_fast(t);
-        }, acc[0], acc[1]);
-        llmax = acc[0];
-        amax = pymax(0.0, -(llmax + dlogl) / (acc[1] - S));
-        for (int i = 0; i < 10; ++i) {
-            f0f1(amax);
-            double f0 = acc[0] - amax * S + dlogl - llmax;
-            double f1 = acc[1] - S;
-            amax = amax - f0 / f1;
-            if (fabs(f0) < 0.1) break;
-        }
-    } else {           // core.py:881-895
-        cd.logsum([=](double w, double &t, double &g) {
-            t = fma(aopt, w, 1.0 - w);
-            double q = w * rcp_fast(t);
-            g = q * q;
-        }, acc[0], acc[1]);
-        llmax = acc[0] - S * aopt;
-        double f2 = fabs(acc[1]);
-        amax = aopt + sqrt(2 * dlogl / f2);
-        for (int i = 0; i < 5; ++i) {
-            f0f1(amax);
-            double f0 = acc[0] - amax * S + dlogl - llmax;
-            double f1 = acc[1] - S;
-            amax = amax - f0 / f1;
-            if (fabs(f0) < 0.1) break;
-        }
-        if (!include_zero && aopt > 0) {   // core.py:897-914
-            double min_a = cd.maxof([](double w) { return 1 - 1. / w; }) + 1e-6;
-            amin = pymax(min_a, aopt - sqrt(2 * dlogl / f2));
-            for (int i = 0; i < 5; ++i) {
-                f0f1(amin);
-                double f0 = acc[0] - amin * S + dlogl - llmax;
-                double f1 = acc[1] - S;
-                amin = pymax(min_a, amin - f0 / f1);
-                if (fabs(f0) < 0.1) break;
-            }
-        }
-    }
-    amin = pymax(0.0, amin);   // core.py:916
-    r.amin = amin;
-    r.amax = amax;
-    r.llmax = llmax;
-    return r;
-}
-
-// numpy.linspace(amin, amax, npt)[i]
-__device__ __forceinline__ double grid_point(double amin, double amax, double step, int i, int npt)
-{
-#pragma clang fp contract(off)   // numpy rounds the product before the sum
-    if (i == npt - 1 && npt > 1) return amax;
-    double prod = (double)i * step;
-    return prod + amin;
-}
-
 // wts = p.we once more, as a parameter that promises not to alias the outputs:
 // that is what lets the compiler read weights at wave-uniform addresses with
 // scalar loads.
@@ -707,10 +631,17 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_logpdf: swap needs B");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
-    size_t smem = (size_t)LP_CH * npt * sizeof(double);
-    dim3 grid((unsigned)ceil_div(ncell, LP_CH));
-    hipLaunchKernelGGL(cell_logpdf_kernel, grid, dim3(256), smem, st, p, we, aopt, dlogl, npt,
-                       include_zero, dom, cod, flags);
+    int gl, gr;
+    if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
+        // sparse cells: groups of one to four lanes per cell (cells_group.hip)
+        godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
+                                          swap, dom, cod, flags, st);
+    } else {
+        size_t smem = (size_t)LP_CH * npt * sizeof(double);
+        dim3 grid((unsigned)ceil_div(ncell, LP_CH));
+        hipLaunchKernelGGL(cell_logpdf_kernel, grid, dim3(256), smem, st, p, we, aopt, dlogl, npt,
+                           include_zero, dom, cod, flags);
+    }
     GODOT_LAUNCH_CHECK("godot_cell_logpdf");
     return GODOT_OK;
 }

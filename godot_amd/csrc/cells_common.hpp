@@ -11,6 +11,10 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
                       const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
                       const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
                       hipStream_t st);
+void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                         const double *S, const double *B, int64_t ncell, const double *aopt, double dlogl,
+                         int npt, int include_zero, int swap, double *dom, double *cod, int32_t *flags,
+                         hipStream_t st);
 }
 
 namespace {
@@ -179,6 +183,68 @@ struct CellData {
         ex = team_sum_i32<T>(ex);
         gsum = team_sum<T>(gs);
         logs = log_scaled(pr, ex);
+    }
+
+    // logs = sum over the cell of log(t_i), gsum = sum of gf(w_i, 1/t_i), with
+    // t_i = den(w_i) > 0; den(0) must be 1 and gf(0, .) must be 0 (zero padding).
+    // The logarithm is taken of the running product, the reciprocals four at a time.
+    template <class DEN, class GF>
+    __device__ __forceinline__ void logsum_rcp(DEN den, GF gf, double &logs, double &gsum) const
+    {
+        double pr = 1.0, gs = 0.0;
+        int ex = 0, k = 0;
+        auto renorm = [&]() {
+            ex += __builtin_amdgcn_frexp_exp(pr);
+            pr = __builtin_amdgcn_frexp_mant(pr);
+        };
+        if (in_regs && R % 4 == 0) {
+#pragma unroll
+            for (int r = 0; r + 3 < R; r += 4) {
+                const double d0 = den(w[r]), d1 = den(w[r + 1]), d2 = den(w[r + 2]), d3 = den(w[r + 3]);
+                double x0, x1, x2, x3;
+                rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+                gs += gf(w[r], x0);
+                gs += gf(w[r + 1], x1);
+                gs += gf(w[r + 2], x2);
+                gs += gf(w[r + 3], x3);
+                pr *= (d0 * d1) * (d2 * d3);
+                if ((r & 4) != 0) renorm();
+            }
+        } else if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double d = den(w[r]);
+                gs += gf(w[r], rcp_fast1(d));
+                pr *= d;
+                if ((r & 7) == 7) renorm();
+            }
+        } else {
+            for (int64_t i = lane; i < n; i += T) {
+                const double wv = ld(i), d = den(wv);
+                gs += gf(wv, rcp_fast1(d));
+                pr *= d;
+                if ((++k & 7) == 0) renorm();
+            }
+        }
+        renorm();
+        pr = team_prod<T>(pr);   // factors in [0.5, 1): at worst 2^-64
+        ex = team_sum_i32<T>(ex);
+        gsum = team_sum<T>(gs);
+        logs = log_scaled(pr, ex);
+    }
+
+    // largest weight of the cell (-inf for an empty cell)
+    __device__ __forceinline__ double wmax() const
+    {
+        double m = -INFINITY;
+        if (in_regs) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (has(r)) m = fmax(m, w[r]);
+        } else {
+            for (int64_t i = lane; i < n; i += T) m = fmax(m, ld(i));
+        }
+        return team_max<T>(m);
     }
 
     // sum over the cell of log(t1_i) - log(t2_i), f(w, t1, t2): one log of the
@@ -514,6 +580,83 @@ __device__ double test_statistic(const CD &cd, double S, double aopt)
         t1 = fma(aopt, w, t2);
     });
     return 2 * (dl - S * aopt);
+}
+
+struct Support {
+    double amin, amax, llmax;
+};
+
+// Support of the profile (core.py:862-916): the interval on which logL stays
+// within dlogl of its maximum, found by a few Newton steps on each side.
+template <class CD>
+__device__ Support support_search(const CD &cd, double S, double aopt, double dlogl,
+                                  bool include_zero)
+{
+    Support r;
+    double amin = 0.0, amax, llmax;
+    double acc[2];
+    // logL(a) + S a and its derivative + S; alpha w + (1 - w) formed as 1 + (alpha - 1) w
+    auto f0f1 = [&](double a) {
+        const double am1 = a - 1.0;
+        cd.logsum_rcp([=](double w) { return fma(am1, w, 1.0); },
+                      [](double w, double x) { return w * x; }, acc[0], acc[1]);
+    };
+    if (aopt == 0) {   // core.py:869-880
+        cd.logsum_rcp([](double w) { return 1.0 - w; },
+                      [](double w, double x) { return w * x; }, acc[0], acc[1]);
+        llmax = acc[0];
+        amax = pymax(0.0, -(llmax + dlogl) * rcp_fast(acc[1] - S));
+        for (int i = 0; i < 10; ++i) {
+            f0f1(amax);
+            double f0 = acc[0] - amax * S + dlogl - llmax;
+            double f1 = acc[1] - S;
+            amax = amax - f0 * rcp_fast(f1);
+            if (fabs(f0) < 0.1) break;
+        }
+    } else {           // core.py:881-895
+        const double am1 = aopt - 1.0;
+        cd.logsum_rcp([=](double w) { return fma(am1, w, 1.0); },
+                      [](double w, double x) {
+                          const double q = w * x;
+                          return q * q;
+                      }, acc[0], acc[1]);
+        llmax = acc[0] - S * aopt;
+        const double half = sqrt(2 * dlogl * rcp_fast(fabs(acc[1])));
+        amax = aopt + half;
+        for (int i = 0; i < 5; ++i) {
+            f0f1(amax);
+            double f0 = acc[0] - amax * S + dlogl - llmax;
+            double f1 = acc[1] - S;
+            amax = amax - f0 * rcp_fast(f1);
+            if (fabs(f0) < 0.1) break;
+        }
+        if (!include_zero && aopt > 0) {   // core.py:897-914
+            // max over the photons of 1 - 1/w is 1 - 1/max(w)
+            double min_a = (1 - 1. / cd.wmax()) + 1e-6;
+            amin = pymax(min_a, aopt - half);
+            for (int i = 0; i < 5; ++i) {
+                f0f1(amin);
+                double f0 = acc[0] - amin * S + dlogl - llmax;
+                double f1 = acc[1] - S;
+                amin = pymax(min_a, amin - f0 * rcp_fast(f1));
+                if (fabs(f0) < 0.1) break;
+            }
+        }
+    }
+    amin = pymax(0.0, amin);   // core.py:916
+    r.amin = amin;
+    r.amax = amax;
+    r.llmax = llmax;
+    return r;
+}
+
+// numpy.linspace(amin, amax, npt)[i]
+__device__ __forceinline__ double grid_point(double amin, double amax, double step, int i, int npt)
+{
+#pragma clang fp contract(off)   // numpy rounds the product before the sum
+    if (i == npt - 1 && npt > 1) return amax;
+    double prod = (double)i * step;
+    return prod + amin;
 }
 
 template <int T>

@@ -86,6 +86,53 @@ struct GroupCell {
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
     }
 
+    // logs = sum over the cell of log(t_i), gsum = sum of gf(w_i, 1/t_i), t_i = den(w_i):
+    // one logarithm of the running product, reciprocals four at a time
+    template <class DEN, class GF>
+    __device__ __forceinline__ void logsum_rcp(DEN den, GF gf, double &logs, double &gsum) const
+    {
+        double pr = 1.0, gs = 0.0;
+        int ex = 0;
+        auto renorm = [&]() {
+            ex += __builtin_amdgcn_frexp_exp(pr);
+            pr = __builtin_amdgcn_frexp_mant(pr);
+        };
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+            const double d0 = den(w[r]), d1 = den(w[r + 1]), d2 = den(w[r + 2]), d3 = den(w[r + 3]);
+            double x0, x1, x2, x3;
+            rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+            gs += gf(w[r], x0);
+            gs += gf(w[r + 1], x1);
+            gs += gf(w[r + 2], x2);
+            gs += gf(w[r + 3], x3);
+            pr *= (d0 * d1) * (d2 * d3);
+            if ((r & 4) != 0) renorm();
+        }
+        int k = 0;
+        for (int j = SLOTS + q; j < n; j += L) {
+            const double wv = tail(j), d = den(wv);
+            gs += gf(wv, rcp_fast1(d));
+            pr *= d;
+            if ((++k & 7) == 0) renorm();
+        }
+        renorm();
+        reduce_prod(pr, ex);
+        gsum = team_sum<L>(gs);
+        logs = log_mant(pr, ex);
+    }
+
+    // largest weight of the cell (-inf for an empty cell)
+    __device__ __forceinline__ double wmax() const
+    {
+        double m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r * L + q < n) m = fmax(m, w[r]);
+        for (int j = SLOTS + q; j < n; j += L) m = fmax(m, tail(j));
+        return team_max<L>(m);
+    }
+
     // product over the cell of f(w) as a mantissa in [0.5, 1) and an exponent
     template <class F>
     __device__ __forceinline__ void prod(F f, double &m, int &e) const
@@ -617,6 +664,237 @@ __global__ __launch_bounds__(64, 4) void cell_fit_restart_bx_kernel(CellArgs p, 
     cell_fit_restart_body<L, R, false>(p, beta, beta0, alpha, ts, flags);
 }
 
+// ---------------------------------------------------------------------------
+// get_logpdf (core.py:851-932) for sparse cells: the maximum (when none is
+// given), the adaptive support and the npt-point profile of every cell.
+// A wavefront owns 64/L cells.  Maximum and support are found with one group
+// of L lanes per cell, as in the fit kernel; the grid is then evaluated one
+// cell at a time by all 64 lanes (the cell's weights are wave-uniform there:
+// scalar loads), LP_PPL points per lane, and written straight to memory in
+// rows.  The maximum of the grid is compared with the likelihood at the centre
+// and the cell is re-centred and done again if they disagree (core.py:923-929).
+// No LDS, no barrier.
+// ---------------------------------------------------------------------------
+constexpr int GP_PPL = 4;
+constexpr int GP_MAX_RECENTRE = 50;
+
+template <int L, int R>
+__global__ __launch_bounds__(64, 4) void cell_logpdf_group_kernel(CellArgs p, const double *__restrict__ wts,
+                                                                  const double *__restrict__ aopt_in,
+                                                                  double dlogl, int npt, int include_zero,
+                                                                  double *__restrict__ dom,
+                                                                  double *__restrict__ cod,
+                                                                  int32_t *__restrict__ flags)
+{
+    constexpr int CW = 64 / L;
+    constexpr int SLOTS = L * R;
+    using GC = GroupCell<L, R>;
+    const int lane = threadIdx.x;
+    const int q = lane % L, ci = lane / L;
+    const int64_t cell0 = (int64_t)blockIdx.x * CW;
+    const int64_t cell = cell0 + ci;
+    const bool have = cell < p.ncell;
+    const bool swap = p.swap != 0;
+
+    int64_t lo = 0, hi = 0;
+    bool bad = false;
+    double S = 0.0;
+    if (have) {
+        lo = p.lo[cell];
+        hi = p.hi[cell];
+        bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+        S = swap ? p.B[cell] : p.S[cell];
+    }
+    const int64_t n64 = (have && !bad) ? hi - lo : 0;
+    const bool big = n64 > 8 * SLOTS;          // maximum and support by the whole wavefront
+    const int n = big ? 0 : (int)n64;
+    GC gc;
+    gather_cell(gc, p.we + (bad ? 0 : lo), n, q, swap);
+
+    // state of this lane's cell: 0 = to do, 1 = done, 2 = absent or failed
+    int state = (have && !bad) ? 0 : 2;
+    int fl = (have && bad) ? GODOT_F_FAILED : 0;
+    double aopt = qnan();
+    if (state == 0) {
+        if (aopt_in) {
+            aopt = aopt_in[cell];
+        } else if (!big) {
+            aopt = fit_alpha(gc, S, 1.0, 1.0, fl);
+            if (fl & GODOT_F_FAILED) state = 2;
+        }
+    }
+    // big cells: all 64 lanes on one cell at a time
+    if (!aopt_in) {
+        unsigned long long bigs = __ballot((big && state == 0 && q == 0) ? 1 : 0);
+        while (bigs) {
+            const int src = __builtin_ctzll(bigs);
+            bigs &= bigs - 1;
+            const int64_t lo_s = readlane_i64(lo, src), hi_s = readlane_i64(hi, src);
+            const double S_s = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
+            StreamCell<64> sc;
+            stream_load(sc, p.we + lo_s, hi_s - lo_s, lane, swap);
+            int bfl = 0;
+            const double ab = fit_alpha(sc, S_s, 1.0, 1.0, bfl);
+            if (lane / L == src / L) {
+                aopt = ab;
+                fl = bfl;
+                if (bfl & GODOT_F_FAILED) state = 2;
+            }
+        }
+    }
+
+    double amin = 0.0, amax = 0.0, llmax = 0.0, step = 0.0;
+    for (int round = 0; round <= GP_MAX_RECENTRE; ++round) {
+        // support of the cells still to do
+        if (state == 0 && !big) {
+            const Support sp = support_search(gc, S, aopt, dlogl, include_zero != 0);
+            amin = sp.amin;
+            amax = sp.amax;
+            llmax = sp.llmax;
+        }
+        unsigned long long bigs = __ballot((big && state == 0 && q == 0) ? 1 : 0);
+        while (bigs) {
+            const int src = __builtin_ctzll(bigs);
+            bigs &= bigs - 1;
+            const int64_t lo_s = readlane_i64(lo, src), hi_s = readlane_i64(hi, src);
+            const double S_s = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
+            const double a_s = __longlong_as_double(readlane_i64(__double_as_longlong(aopt), src));
+            StreamCell<64> sc;
+            stream_load(sc, p.we + lo_s, hi_s - lo_s, lane, swap);
+            const Support sp = support_search(sc, S_s, a_s, dlogl, include_zero != 0);
+            if (lane / L == src / L) {
+                amin = sp.amin;
+                amax = sp.amax;
+                llmax = sp.llmax;
+            }
+        }
+        if (state == 0) step = (npt > 1) ? (amax - amin) / (double)(npt - 1) : 0.0;
+
+        // grid evaluation, one cell at a time
+        unsigned long long todo = __ballot((state == 0 && q == 0) ? 1 : 0);
+        if (!todo) break;
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int64_t cg = cell0 + src / L;
+            const int64_t lo_c = readlane_i64(lo, src);
+            const int n_c = (int)(readlane_i64(hi, src) - lo_c);
+            const double amin_c = __longlong_as_double(readlane_i64(__double_as_longlong(amin), src));
+            const double amax_c = __longlong_as_double(readlane_i64(__double_as_longlong(amax), src));
+            const double step_c = __longlong_as_double(readlane_i64(__double_as_longlong(step), src));
+            const double ll_c = __longlong_as_double(readlane_i64(__double_as_longlong(llmax), src));
+            const double S_c = __longlong_as_double(readlane_i64(__double_as_longlong(S), src));
+            const double *w = wts + lo_c;
+            double best = -INFINITY;
+            int ibest = npt;
+            bool anynan = false;
+            for (int i0 = 0; i0 < npt; i0 += 64 * GP_PPL) {
+                double av[GP_PPL], am1[GP_PPL], pr[GP_PPL];
+                int ex[GP_PPL];
+#pragma unroll
+                for (int u = 0; u < GP_PPL; ++u) {
+                    int i = i0 + u * 64 + lane;
+                    i = i < npt ? i : npt - 1;
+                    av[u] = grid_point(amin_c, amax_c, step_c, i, npt);
+                    am1[u] = av[u] - 1.0;
+                    pr[u] = 1.0;
+                    ex[u] = 0;
+                }
+                int j = 0;
+                if (!swap) {
+                    // alpha w + (1 - w) as 1 + (alpha - 1) w
+                    for (; j + 8 <= n_c; j += 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const double wj = w[j + k];
+#pragma unroll
+                            for (int u = 0; u < GP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < GP_PPL; ++u) {
+                            ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                            pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                        }
+                    }
+                    for (; j < n_c; ++j) {
+                        const double wj = w[j];
+#pragma unroll
+                        for (int u = 0; u < GP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
+                    }
+                } else {
+                    // on complemented weights: alpha (1 - w) + w = alpha - (alpha - 1) w
+                    for (; j < n_c; ++j) {
+                        const double wj = w[j];
+#pragma unroll
+                        for (int u = 0; u < GP_PPL; ++u) pr[u] *= fma(-am1[u], wj, av[u]);
+                        if ((j & 7) == 7) {
+#pragma unroll
+                            for (int u = 0; u < GP_PPL; ++u) {
+                                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GP_PPL; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i < npt) {
+                        const double v = log_scaled(pr[u], ex[u]) - S_c * av[u];
+                        dom[cg * npt + i] = av[u];
+                        cod[cg * npt + i] = v - ll_c;
+                        if (isnan(v)) anynan = true;
+                        if (v > best) {        // ascending i per lane: keeps the first maximum
+                            best = v;
+                            ibest = i;
+                        }
+                    }
+                }
+            }
+            // agreement of the grid maximum with the likelihood at the centre (core.py:923-929);
+            // numpy's argmax returns the first NaN if there is one, and the reference's
+            // comparison is then false: the grid is accepted
+            const double gbest = team_max<64>(best);
+            const bool nan_c = __any(anynan ? 1 : 0);
+            const bool agree = nan_c || !(fabs(gbest - ll_c) > 0.05);
+            int inew = 0;
+            if (!agree) {
+                int cand = (best == gbest) ? ibest : npt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int other = __shfl_xor(cand, o, WAVE);
+                    cand = other < cand ? other : cand;
+                }
+                inew = cand >= npt ? 0 : cand;
+            }
+            if (lane / L == src / L) {
+                if (agree) {
+                    state = 1;
+                } else if (round == GP_MAX_RECENTRE) {
+                    state = 2;
+                    fl |= GODOT_F_FAILED;
+                } else {
+                    aopt = grid_point(amin, amax, step, inew, npt);
+                    fl |= GODOT_F_RECENTRED;
+                }
+            }
+        }
+    }
+
+    // cells without a profile: rows of NaN
+    unsigned long long nans = __ballot((have && state == 2 && q == 0) ? 1 : 0);
+    while (nans) {
+        const int src = __builtin_ctzll(nans);
+        nans &= nans - 1;
+        const int64_t cg = cell0 + src / L;
+        for (int i = lane; i < npt; i += 64) {
+            dom[cg * npt + i] = qnan();
+            cod[cg * npt + i] = qnan();
+        }
+    }
+    if (flags && have && q == 0) flags[cell] = fl;
+}
+
 }   // namespace
 
 namespace godot_detail {
@@ -678,6 +956,24 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     GK_LAUNCH_INPLACE(4, 16)
 #undef GK_LAUNCH_INPLACE
 #undef GK_LAUNCH_TWO
+}
+
+void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                         const double *S, const double *B, int64_t ncell, const double *aopt, double dlogl,
+                         int npt, int include_zero, int swap, double *dom, double *cod, int32_t *flags,
+                         hipStream_t st)
+{
+    CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    dim3 grid((unsigned)ceil_div(ncell, (int64_t)(64 / L))), block(64);
+#define GP_LAUNCH(L_, R_)                                                                             \
+    if (L == L_ && R == R_)                                                                           \
+        hipLaunchKernelGGL((cell_logpdf_group_kernel<L_, R_>), grid, block, 0, st, p, we, aopt, dlogl, \
+                           npt, include_zero, dom, cod, flags);
+    GP_LAUNCH(1, 8)
+    GP_LAUNCH(1, 16)
+    GP_LAUNCH(2, 16)
+    GP_LAUNCH(4, 16)
+#undef GP_LAUNCH
 }
 
 }   // namespace godot_detail

@@ -249,6 +249,61 @@ def test_fit_sparse_cell_kernels(mean, variant):
         assert (depth > 0).any()        # the restart path was exercised
 
 
+@pytest.mark.parametrize('mean,variant', [(4, 'plain'), (12.5, 'plain'), (22, 'plain'), (22, 'swap'),
+                                          (22, 'outliers'), (22, 'given'), (40, 'plain'), (22, 'npt300')])
+def test_logpdf_sparse_cell_kernels(mean, variant):
+    """Profile grids of the sparse-cell kernel in every shape against the
+    oracle's get_logpdf: centre found by the kernel or given, complemented
+    weights, a few cells far larger than the rest, more points than one
+    sweep of the wavefront holds."""
+    from godot_amd import ops
+    dev = _dev()
+    ncell = 3000
+    rng = np.random.default_rng(int(mean * 10) + len(variant) + 77)
+    cnt = rng.poisson(mean, ncell).astype(np.int64)
+    if variant == 'outliers':
+        cnt[rng.choice(ncell, 8, replace=False)] = rng.integers(100, 2500, 8)
+        cnt[:3] = 0
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = np.maximum(cnt * 0.17 * rng.uniform(0.3, 3, ncell), 0.05)
+    B = S * 5
+    npt = 300 if variant == 'npt300' else 200
+    wd = torch.from_numpy(we).to(dev)
+    od = torch.from_numpy(off).to(dev)
+    Sd, Bd = torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev)
+    kw = {}
+    if variant == 'swap':
+        cr = ops.CellRanges.from_offsets(1 - wd, od, Bd, Sd)
+        kw['swap'] = True
+    else:
+        cr = ops.CellRanges.from_offsets(wd, od, Sd, Bd)
+    given = None
+    if variant == 'given':
+        given = rng.uniform(0.0, 3.0, ncell)
+        given[::7] = 0.0
+        kw['aopt'] = torch.from_numpy(given).to(dev)
+    dom, cod, flags = ops.cell_logpdf(cr, dlogl=30, npt=npt, **kw)
+    dom, cod, flags = dom.cpu().numpy(), cod.cpu().numpy(), flags.cpu().numpy()
+    assert not (flags & 0x10).any()
+    pick = np.unique(np.concatenate([rng.choice(ncell, 120, replace=False), np.flatnonzero(flags & 0x20)[:40],
+                                     np.flatnonzero(cnt > 64), np.arange(3)]))
+    tol = RTOL * (100 if variant == 'swap' else 1)
+    ncmp = 0
+    with np.errstate(all='ignore'):
+        for c in pick:
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            d, v = cl.get_logpdf(aopt=None if given is None else given[c], dlogl=30, npt=npt)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            if np.isnan(d).any() or np.isnan(v).any():
+                continue      # the reference's own Newton steps left the domain: nothing to compare
+            assert np.abs(dom[c] - d).max() <= tol * max(1.0, np.abs(d).max()), (c, cnt[c], flags[c])
+            assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), (c, cnt[c], flags[c])
+            ncmp += 1
+    assert ncmp > 60
+
+
 def test_joint_fit_meets_reference_likelihood(golden):
     """get_max(profile_background=True): the reference's optimiser (scipy TNC,
     ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
