@@ -678,8 +678,10 @@ __global__ __launch_bounds__(64, 4) void cell_fit_restart_bx_kernel(CellArgs p, 
 constexpr int GP_PPL = 4;
 constexpr int GP_MAX_RECENTRE = 50;
 
+// three wavefronts per SIMD: the registers of a cell's weights stay live across the
+// grid evaluation (measured 3 % faster than four with spills)
 template <int L, int R>
-__global__ __launch_bounds__(64, 4) void cell_logpdf_group_kernel(CellArgs p, const double *__restrict__ wts,
+__global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, const double *__restrict__ wts,
                                                                   const double *__restrict__ aopt_in,
                                                                   double dlogl, int npt, int include_zero,
                                                                   double *__restrict__ dom,
