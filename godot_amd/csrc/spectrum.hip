@@ -4,12 +4,15 @@
 // A real series of (zero-padded) length l is transformed as a complex series
 // of length N = l/2 (even samples -> real parts, odd samples -> imaginary
 // parts) followed by the split into the real transform's bins.  The complex
-// transform is a Stockham autosort FFT: radix-16 passes ping-ponging between
-// two HBM buffers (one thread = one 16-point butterfly held in registers,
-// reads coalesced, writes in runs of >= 256 bytes), plus one radix-2/4/8 pass
-// when log2 N is not a multiple of 4.  Twiddles are computed in registers from
-// an exactly reduced angle, so no table is read.  HBM-bound: each pass moves
-// 32 bytes per complex point.
+// transform is a Stockham autosort FFT ping-ponging between two HBM buffers.
+// Long transforms take radix-256 passes: two radix-16 butterflies per kernel
+// with a transpose through LDS in between, so a 2^24-point transform is three
+// HBM round trips; what is left of log2 N goes in one more pass (radix 2 .. 128).
+// Short transforms (N < 4096) take plain radix-16 passes (one thread = one
+// 16-point butterfly in registers).  Reads are coalesced, writes come in runs
+// of >= 256 bytes.  Twiddles are computed in registers from an exactly reduced
+// angle, so no table is read.  HBM-bound: each pass moves 32 bytes per complex
+// point.
 #include "common.hpp"
 
 namespace {
@@ -127,6 +130,79 @@ __global__ __launch_bounds__(256) void stockham_pass_kernel(const cplx *__restri
     for (int r = 0; r < R; ++r) dst[j0 + r * Ns] = v[r];
 }
 
+// Two Stockham passes in one kernel: radix R = A * 16 (A = 2 .. 16).  A workgroup
+// takes 16 consecutive butterflies of R points; 16 threads share one of them.
+// With r = t + 16 m and q = q_lo + A q_hi:
+//   X[q] = sum_t W_16^(t q_hi) [ W_R^(t q_lo) sum_m W_A^(m q_lo) x_(t + 16 m) ],
+// thread t forms the inner A-point transforms in registers, the bracket goes
+// through LDS (transposed), thread q_lo forms the outer 16-point transforms.
+// One HBM round trip instead of two.  FIRST: the pass with Ns = 1 (no outer
+// twiddles; results of one butterfly are contiguous, so lanes run over q_lo).
+template <int A, bool FIRST>
+__global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restrict__ in,
+                                                             cplx *__restrict__ out, int64_t N, int64_t Ns)
+{
+    constexpr int R = A * 16;
+    // (q_lo, t, jj) with jj fastest; one element of padding per q_lo keeps the
+    // lanes of the FIRST read-back (which run over q_lo) on different banks
+    __shared__ cplx lds[A * 256 + A];
+    const int tid = threadIdx.x;
+    const int t = tid >> 4, jj = tid & 15;
+    const int64_t S = N / R;
+    const int64_t jb = (int64_t)blockIdx.x * 16;
+    const int64_t j = jb + jj;
+    const cplx *src = in + (int64_t)blockIdx.y * N;
+    cplx *dst = out + (int64_t)blockIdx.y * N;
+    cplx v[A];
+#pragma unroll
+    for (int m = 0; m < A; ++m) v[m] = src[j + (int64_t)(t + 16 * m) * S];
+    if (!FIRST) {
+        // x_r *= exp(-2 pi i k r / (Ns R)), r = t + 16 m: exp(-2 pi i k t / (Ns R)) times
+        // powers of exp(-2 pi i 16 k / (Ns R)); both angles are exact binary fractions
+        const int64_t k = j & (Ns - 1);
+        const double th = -(double)k / (double)(Ns * R);
+        double xt = th * (double)t, xb = th * 16.0;
+        xt -= rint(xt);
+        xb -= rint(xb);
+        const cplx wt = expi_cycles(xt);
+        cplx pw[A];
+        pw[0] = cplx{1.0, 0.0};
+        pw[1] = expi_cycles(xb);
+#pragma unroll
+        for (int m = 2; m < A; ++m) pw[m] = cmul(pw[m / 2], pw[m - m / 2]);
+        v[0] = cmul(v[0], wt);
+#pragma unroll
+        for (int m = 1; m < A; ++m) v[m] = cmul(v[m], cmul(wt, pw[m]));
+    }
+    dft<A>(v);
+    {
+        // W_R^(t q_lo)
+        cplx pw[A];
+        pw[0] = cplx{1.0, 0.0};
+        pw[1] = expi_cycles(-(double)t / (double)R);
+#pragma unroll
+        for (int q = 2; q < A; ++q) pw[q] = cmul(pw[q / 2], pw[q - q / 2]);
+#pragma unroll
+        for (int q = 1; q < A; ++q) v[q] = cmul(v[q], pw[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < A; ++q) lds[(q * 16 + t) * 16 + jj + q] = v[q];
+    __syncthreads();
+    const int u = FIRST ? (tid & 15) : (tid >> 4);
+    const int j2 = FIRST ? (tid >> 4) : (tid & 15);
+    if (u < A) {
+        cplx z[16];
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) z[tt] = lds[(u * 16 + tt) * 16 + j2 + u];
+        dft<16>(z);
+        const int64_t jo = jb + j2;
+        const int64_t ko = jo & (Ns - 1);
+        const int64_t obase = (jo - ko) * R + ko;
+#pragma unroll
+        for (int h = 0; h < 16; ++h) dst[obase + (int64_t)(u + A * h) * Ns] = z[h];
+    }
+}
+
 // Complex forward FFT of `batch` series of power-of-two length N >= 2.
 // Returns the buffer (a or b) that holds the result.
 cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
@@ -156,7 +232,36 @@ cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
         src = dst;
         dst = t;
     };
-    // the odd-sized pass goes first (Ns = 1: no twiddles)
+    auto launch_fused = [&](int A, bool first) {
+        const int R = A * 16;
+        dim3 grid((unsigned)(N / R / 16), (unsigned)batch);
+#define FUSED(A_)                                                                                     \
+    if (A == A_) {                                                                                    \
+        if (first)                                                                                    \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, true>), grid, dim3(256), 0, st,             \
+                               (const cplx *)src, dst, N, Ns);                                        \
+        else                                                                                          \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, false>), grid, dim3(256), 0, st,            \
+                               (const cplx *)src, dst, N, Ns);                                        \
+    }
+        FUSED(2) FUSED(4) FUSED(8) FUSED(16)
+#undef FUSED
+        Ns *= R;
+        cplx *t = src;
+        src = dst;
+        dst = t;
+    };
+    if (lg >= 12) {
+        // radix-256 passes fused through LDS (one HBM round trip each), then what
+        // is left of log2 N: up to four bits as a plain pass, five to seven as a
+        // fused pass of radix 32 .. 128
+        const int nfused = lg / 8, rem = lg % 8;
+        for (int p = 0; p < nfused; ++p) launch_fused(16, p == 0);
+        if (rem >= 5) launch_fused(1 << (rem - 4), false);
+        else if (rem) launch(1 << rem);
+        return src;
+    }
+    // short transforms: the odd-sized pass goes first (Ns = 1: no twiddles)
     int rem = lg % 4;
     if (rem) launch(1 << rem);
     for (int p = 0; p < lg / 4; ++p) launch(16);

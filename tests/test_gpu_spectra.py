@@ -26,7 +26,8 @@ def _ts(g):
 @pytest.mark.parametrize('l,n', [(2, 2), (3, 3), (5, 4), (6, 6), (7, 9), (12, 12), (1000, 1000),
                                  (10362, 10362), (99991, 60000), (786432, 786432), (4, 3), (8, 8), (16, 5), (32, 32), (64, 33), (256, 256), (1024, 700),
                                  (4096, 4096), (1 << 13, 5000), (1 << 16, 1 << 16), (1 << 17, 99999),
-                                 (1 << 20, 300000)])
+                                 (1 << 20, 300000), (1 << 14, 1 << 14), (1 << 15, 20000), (1 << 18, 1 << 18), (1 << 19, 400000),
+                                 (1 << 21, 1 << 21), (1 << 22, 3000000), (1 << 23, 1 << 23), (1 << 25, 1 << 25)])
 def test_rfft_matches_numpy(l, n):
     from godot_amd import ops
     rng = np.random.default_rng(l + n)
