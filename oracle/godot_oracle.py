@@ -868,6 +868,117 @@ def z2m_exact(t, w, f0, df, j, m):
 T0 = 239557417.0
 
 
+# ----------------------------------------------------------------------
+# Bayesian Blocks on the cached profiles: core.py:1108-1208, 1338-1389
+# ----------------------------------------------------------------------
+BB_NGRID = 1000
+
+
+def bb_fitness(dom, cod, i0, i1):
+    """core.py:1108-1136: for the cells i0 .. i1-1 the summed log profile of
+    every block that ends with cell i1-1, on a 1000-point grid over the
+    support of that last cell.  Column j of the result belongs to the
+    block that starts at cell i0 + j: 2 * (maximum of the sum, alpha there)."""
+    grid = np.linspace(dom[i1 - 1][0], dom[i1 - 1][-1], BB_NGRID)
+    out = np.empty((2, i1 - i0))
+    acc = np.zeros(BB_NGRID)
+    for back in range(i1 - i0):
+        c = i1 - 1 - back
+        acc += np.interp(grid, dom[c], cod[c], left=-np.inf, right=-np.inf)
+        k = np.argmax(acc)
+        out[:, -(back + 1)] = acc[k], grid[k]
+    return out * 2
+
+
+def bb_partition(fit0, prior=2):
+    """core.py:1146-1169 / 1183-1202: the dynamic programme over the first
+    rows (fitness values) of bb_fitness(0, i+1), i = 0 .. ncell-1, and the
+    walk back through the change points.  Returns indices, best[-1]."""
+    ncell = len(fit0)
+    best = np.asarray([-np.inf] * (ncell + 1))
+    last = np.empty(ncell, dtype=int)
+    last[0] = 0
+    best[0] = 0
+    best[1] = fit0[0][0] - prior
+    for i in range(1, ncell):
+        a = fit0[i] - prior + best[:i + 1]
+        r = np.argmax(a)
+        best[i + 1] = a[r]
+        last[i] = r
+    cps = []
+    k = last[-1]
+    while k > 0:
+        cps.append(k)
+        k = last[k - 1]
+    indices = np.append(0, np.asarray(cps, dtype=int)[::-1])
+    return indices, best[-1], best, last
+
+
+def do_bb(dom, cod, prior=2):
+    """core.py:1138-1177: indices, total fitness, variability TS and its
+    degrees of freedom, and the fitness rows."""
+    ncell = len(dom)
+    rows = [bb_fitness(dom, cod, 0, i + 1) for i in range(ncell)]
+    indices, best_fitness, _, _ = bb_partition([r[0] for r in rows], prior)
+    var_dof = len(indices) - 1
+    var_ts = (best_fitness - rows[-1][0][0]) + prior * var_dof
+    return indices, best_fitness + len(indices) * prior, var_ts, var_dof, rows
+
+
+def merge_cells(cells):
+    """core.py:200-210 (cell_from_cells) on (tstart, tstop, exp, ti, we,
+    SonB) tuples: one cell for several."""
+    cells = sorted(cells, key=lambda c: c[0])
+    we = np.concatenate([c[4] for c in cells])
+    ti = np.concatenate([c[3] for c in cells])
+    exp = np.asarray([c[2] for c in cells]).sum()
+    bexp = np.asarray([c[2] / c[5] for c in cells]).sum()
+    return cells[0][0], cells[-1][1], exp, ti, we, exp / bexp
+
+
+def single_cell_flux(cl, conf=(0.05, 0.95)):
+    """core.py:996-1026 (CellLogLikelihood.get_flux, background fixed)."""
+    aopt = cl.get_max()
+    dom, cod = cl.get_pdf(aopt=aopt)
+    k = np.argmax(cod)
+    if abs(dom[k] - aopt) > 0.1:
+        aopt = cl.get_max(guess=dom[k])
+        dom, cod = cl.get_pdf(aopt=aopt, npt=200)
+        k = np.argmax(cod)
+        if abs(dom[k] - aopt) > 0.1:
+            aopt = dom[k]
+    ts = cl.get_ts(aopt)
+    cdf = cumulative_trapezoid(cod, dom, initial=0)
+    cdf *= 1. / cdf[-1]
+    idx = np.searchsorted(cdf, conf)
+    ihi, ilo = idx, idx - 1
+    m = (cdf[ihi] - cdf[ilo]) / (dom[ihi] - dom[ilo])
+    return aopt, ts, dom[ilo] + (np.asarray(conf) - cdf[ilo]) / m
+
+
+def bb_lightcurve(cells, dom, cod, tsmin=4, bb_prior=8):
+    """core.py:1338-1389 for (tstart, tstop, exp, ti, we, SonB) tuples and
+    their cached profiles; rows as in raw_lightcurve.  Returns rows and
+    the block boundaries (cell indices, the last one = ncell)."""
+    idx = do_bb(dom, cod, prior=bb_prior)[0]
+    idx = np.append(idx, len(cells))
+    rows = np.empty([len(idx) - 1, 6])
+    for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
+        t0, t1, exp, ti, we, sonb = merge_cells(cells[i0:i1])
+        cl = CellLike(we, exp, sonb)
+        if cl.S == 0:
+            rows[b] = np.nan
+            continue
+        tmid = 0.5 * (t0 + t1)
+        terr = (tmid - t0) / 86400
+        aopt, ts, xc = single_cell_flux(cl, conf=[0.16, 0.84])
+        if ts <= tsmin:
+            rows[b] = met2mjd(tmid), terr, xc[1], 0, -1, ts
+        else:
+            rows[b] = met2mjd(tmid), terr, aopt, aopt - xc[0], xc[1] - aopt, ts
+    return rows, idx
+
+
 def synth(nph, years=10., seed=7):
     rng = np.random.default_rng(seed)
     nrow = int(years * 365.25 * 86400 / 30)

@@ -196,3 +196,38 @@ def test_z2m_against_exact_phases():
     for n, jj in enumerate(j):
         ze = orc.z2m_exact(t, w, f0, df, jj, 2)
         assert abs(z[n] - ze) <= 1e-11 * max(1., abs(ze))
+
+
+def test_bayesian_blocks_restatement_equals_reference(golden):
+    """fitness / do_bb / do_top_hat / get_bb_lightcurve (core.py:1108-1225, 1338-1389)."""
+    g = golden('bayesian_blocks.npz')
+    dom, cod = g['dom'], g['cod']
+    n = len(dom)
+    idx8, total8, vts8, vdof8, rows = orc.do_bb(dom, cod, prior=8)
+    assert np.array_equal(np.concatenate([r[0] for r in rows]), g['fit_val'])
+    assert np.array_equal(np.concatenate([r[1] for r in rows]), g['fit_arg'])
+    assert np.array_equal(idx8, g['bb8_indices'])
+    assert np.array_equal(np.array([total8, vts8, vdof8], dtype=float), g['bb8_scalars'])
+    idx2, best2, _, _ = orc.bb_partition([r[0] for r in rows], prior=2)
+    assert np.array_equal(idx2, g['bb2_indices'])
+    assert best2 + len(idx2) * 2 == g['bb2_scalars'][0]
+    assert np.array_equal(orc.bb_fitness(dom, cod, 5, 40), g['fitness_5_40'])
+    off = np.append(0, np.cumsum(g['counts']))
+    cells = [(g['starts'][i], g['stops'][i], g['exp'][i], g['ti'][off[i]:off[i + 1]],
+              g['we'][off[i]:off[i + 1]], g['SonB'][i]) for i in range(n)]
+    with np.errstate(all='ignore'):
+        lc, edges = orc.bb_lightcurve(cells, dom, cod, tsmin=4, bb_prior=8)
+    assert np.array_equal(lc, g['bb_rows'], equal_nan=True)
+    assert np.array_equal(edges, g['bb_idx'])
+    # do_top_hat (core.py:1210-1225): three diagonals of the two maps
+    top = np.empty((2, n, n))
+    ix = np.arange(n)
+    for iv, v in enumerate(rows):
+        top[:, ix[:iv + 1], ix[:iv + 1] + n - (iv + 1)] = v
+        top[:, ix[:iv + 1] + n - (iv + 1), ix[:iv + 1]] = np.nan
+    top[0] += (np.arange(n) * 2)[None, ::-1]
+    top[1] *= 0.5
+    for k in (0, 1):
+        for j, o in enumerate((0, 1, 7)):
+            assert np.array_equal(np.diagonal(top[k], offset=o)[: n - 7], g['top_hat_diag'][k, j], equal_nan=True)
+
