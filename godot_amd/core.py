@@ -21,7 +21,7 @@ __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries'
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
            'met2mjd', 'mjd2met', 'infer_met', 'power_spectrum_fft', 'power_spectrum_simple',
            'power_spectrum_dft', 'fit_harmonics', 'compute_ls', 'get_orbital_modulation', 'z2m',
-           'h_test']
+           'h_test', 'PhaseCellsLogLikelihood', 'FitnessRows']
 
 MJDREF = 51910 + 7.428703703703703e-4
 F64 = torch.float64
@@ -169,6 +169,41 @@ class CellBatch(object):
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
+
+    def merge_blocks(self, edges):
+        """One cell per run of cells edges[b] .. edges[b+1]-1, as cell_from_cells
+        (reference core.py:200-210) makes them: photons concatenated, exposures
+        summed, start of the earliest and stop of the latest member."""
+        h = self._hostcopy()
+        edges = np.asarray(edges, dtype=np.int64)
+        nb = len(edges) - 1
+        lo_h, hi_h = h['lo'], h['hi']
+        contiguous = all(np.array_equal(hi_h[s:e - 1], lo_h[s + 1:e]) for s, e in zip(edges[:-1], edges[1:]))
+        dev = self.device
+        if contiguous:
+            we, ti = self.we, self.ti
+            lo = _to_dev(lo_h[edges[:-1]], dev, I64)
+            hi = _to_dev(hi_h[edges[1:] - 1], dev, I64)
+        else:
+            # gather the members' photons into a new list, block after block
+            cnt = hi_h - lo_h
+            src = np.concatenate([np.arange(l, u) for l, u in zip(lo_h, hi_h)] or [np.empty(0, np.int64)])
+            src = _to_dev(src.astype(np.int64), dev, I64)
+            we, ti = ops.gather(self.we, src), ops.gather(self.ti, src)
+            off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+            lo = _to_dev(off[edges[:-1]], dev, I64)
+            hi = _to_dev(off[edges[1:]], dev, I64)
+        starts = np.empty(nb)
+        stops = np.empty(nb)
+        sexp = np.empty(nb)
+        bexp = np.empty(nb)
+        for b, (s, e) in enumerate(zip(edges[:-1], edges[1:])):
+            starts[b] = h['starts'][s:e].min()
+            stops[b] = h['stops'][s:e][np.argmax(h['starts'][s:e])]
+            sexp[b] = np.asarray(h['sexp'][s:e]).sum()
+            bexp[b] = np.asarray(h['bexp'][s:e]).sum()
+        return CellBatch(we, ti, lo, hi, _to_dev(starts, dev), _to_dev(stops, dev), _to_dev(sexp, dev),
+                         _to_dev(bexp, dev))
 
 
 def _as_batch(cells, device=None):
@@ -353,6 +388,30 @@ class CellLogLikelihood(object):
         np.exp(cod, out=cod)
         return dom, cod * (1. / simpson(cod, x=dom))
 
+    def get_flux(self, conf=[0.05, 0.95], profile_background=False):
+        """(aopt, ts, xconf) of the cell (reference core.py:996-1026)."""
+        from scipy.integrate import cumulative_trapezoid
+        aopt = self.get_max(profile_background=profile_background)
+        if profile_background:
+            aopt = aopt[0]
+        dom, cod = self.get_pdf(aopt=aopt, profile_background=profile_background)
+        amax = np.argmax(cod)
+        if abs(dom[amax] - aopt) > 0.1:
+            aopt = self.get_max(guess=dom[amax], profile_background=profile_background)
+            if profile_background:
+                aopt = aopt[0]
+            dom, cod = self.get_pdf(aopt=aopt, profile_background=profile_background, npt=200)
+            amax = np.argmax(cod)
+            if abs(dom[amax] - aopt) > 0.1:
+                aopt = dom[amax]
+        ts = self.get_ts(aopt=aopt, profile_background=profile_background)
+        cdf = cumulative_trapezoid(cod, dom, initial=0)
+        cdf *= 1. / cdf[-1]
+        indices = np.searchsorted(cdf, conf)
+        ihi, ilo = indices, indices - 1
+        m = (cdf[ihi] - cdf[ilo]) / (dom[ihi] - dom[ilo])
+        return aopt, ts, dom[ilo] + (np.asarray(conf) - cdf[ilo]) / m
+
     def get_beta_max(self, alpha, guess=1):
         b, _, fl = ops.cell_beta_max(self._cr, float(alpha), guess=float(guess), swap=self._swap,
                                      want_logl=False)
@@ -458,6 +517,103 @@ class CellsLogLikelihood(object):
             return float(lp.sum().cpu())
         return float(ops.cell_loglike(self._cr, at, swap=self._swap).sum().cpu())
 
+    # ---- Bayesian Blocks (reference core.py:1108-1225, 1338-1389) ------------
+    def _fitness_rows(self):
+        if self.fitness_vals is None:
+            fv, fa = ops.bb_fitness(self._dom_d, self._cod_d, ngrid=1000)
+            self.fitness_vals = FitnessRows(fv, fa, len(self.cells))
+        return self.fitness_vals
+
+    def fitness(self, i0, i1):
+        """2 * (maximum, alpha at the maximum) of the summed profiles of the
+        blocks i0 .. i1-1, i0+1 .. i1-1, ..., i1-1 (reference core.py:1108-1136)."""
+        return self._fitness_rows()[i1 - 1][:, i0:]
+
+    def do_bb(self, prior=2):
+        """indices, total fitness, variability TS, its degrees of freedom, fitness
+        rows (reference core.py:1138-1208; the rows are computed once)."""
+        rows = self._fitness_rows()
+        n = len(self.cells)
+        best, last = ops.bb_partition(rows.fit_val, n, prior)
+        best_fitness = float(best[-1].cpu())
+        last = _np(last)
+        cps = []
+        k = last[-1]
+        while k > 0:
+            cps.append(k)
+            k = last[k - 1]
+        indices = np.append(0, np.asarray(cps, dtype=int)[::-1])
+        var_dof = len(indices) - 1
+        var_ts = (best_fitness - rows[n - 1][0][0]) + prior * var_dof
+        return indices, best_fitness + len(indices) * prior, var_ts, var_dof, rows
+
+    _do_bb_cache = do_bb
+
+    def do_top_hat(self):
+        """Top-hat filtered map of TS and flux (reference core.py:1210-1225)."""
+        rows = self.do_bb()[-1]
+        n = len(rows)
+        out = np.full((2, n, n), np.nan)
+        r = np.arange(n)
+        for iv in range(n - 1):          # the full-length row lands on the diagonal, which ends as NaN
+            v = rows[iv]
+            out[:, r[:iv + 1], r[:iv + 1] + n - (iv + 1)] = v
+        out[0] += (np.arange(n) * 2)[None, ::-1]
+        out[1] *= 0.5
+        return out
+
+    def _block_fluxes(self, blocks):
+        """CellLogLikelihood.get_flux(conf=[0.16, 0.84]) of every merged cell
+        (reference core.py:996-1026), batched; the rare cells whose profile
+        maximum and fitted maximum disagree take the reference's refinement
+        one by one."""
+        cr = blocks.ranges()
+        if self.profile_background:
+            aopt, _, _, fl = ops.cell_fit_joint(cr, swap=self._swap)
+            dom, cod, _ = ops.cell_logpdf_profile(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
+            _, lp1, _ = ops.cell_beta_max(cr, aopt, swap=self._swap)
+            _, lp0, _ = ops.cell_beta_max(cr, 0.0, swap=self._swap)
+            ts = 2 * (lp1 - lp0)
+            ts = torch.where((aopt == 0) | (cr.S == 0), torch.zeros_like(ts), ts)
+        else:
+            aopt, ts, fl = ops.cell_fit(cr, swap=self._swap)
+            if bool((fl & 0x10).any().cpu()):
+                raise ValueError('f(a) and f(b) must have different signs')
+            dom, cod, _ = ops.cell_logpdf(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
+        ag, xlo, xhi = ops.profile_quantiles(dom, cod, 0.16, 0.84)
+        aopt, ts, xlo, xhi = _np(aopt), _np(ts), _np(xlo), _np(xhi)
+        for b in np.flatnonzero(np.abs(_np(ag) - aopt) > 0.1):
+            cl = CellLogLikelihood(blocks[int(b)], swap=self._swap, device=blocks.device)
+            a, t, xc = cl.get_flux(conf=[0.16, 0.84], profile_background=self.profile_background)
+            aopt[b], ts[b], xlo[b], xhi[b] = a, t, xc[0], xc[1]
+        return aopt, ts, xlo, xhi
+
+    def get_bb_lightcurve(self, tsmin=4, bb_prior=8, get_indices=False):
+        """Bayesian-Blocks light curve, rows as in get_raw_lightcurve
+        (reference core.py:1338-1389)."""
+        plot_phase = isinstance(self, PhaseCellsLogLikelihood)
+        bb_idx = self.do_bb(prior=bb_prior)[0]
+        bb_idx = np.append(bb_idx, len(self.cells))
+        blocks = self.cells.merge_blocks(bb_idx)
+        aopt, ts, xlo, xhi = self._block_fluxes(blocks)
+        h = blocks._hostcopy()
+        S = h['bexp'] if self._swap else h['sexp']
+        tmid = 0.5 * (h['starts'] + h['stops'])
+        terr = tmid - h['starts']
+        if not plot_phase:
+            terr = terr / 86400
+            tmid = met2mjd(tmid)
+        rows = np.empty([len(bb_idx) - 1, 6])
+        ul = ts <= tsmin
+        rows[:, 0], rows[:, 1], rows[:, 5] = tmid, terr, ts
+        rows[:, 2] = np.where(ul, xhi, aopt)
+        rows[:, 3] = np.where(ul, 0, aopt - xlo)
+        rows[:, 4] = np.where(ul, -1, xhi - aopt)
+        rows[S == 0] = np.nan
+        if get_indices:
+            return rows, bb_idx
+        return rows
+
     def get_raw_lightcurve(self, tsmin=4):
         """(ncell, 6) rows: MJD mid-time, half width (days), flux or upper
         limit, lower error, upper error (-1 for limits), TS."""
@@ -469,6 +625,52 @@ class CellsLogLikelihood(object):
         tmid = 0.5 * (_np(self.cells.starts) + _np(self.cells.stops))
         out[:, 0] = met2mjd(tmid)
         return out
+
+
+class FitnessRows(object):
+    """The reference's `fitness_vals` (a deque of (2, i+1) arrays, core.py:1148-1156)
+    kept on the device as two packed lower triangles; rows are copied to the
+    host when they are read."""
+
+    def __init__(self, fit_val, fit_arg, ncell):
+        self.fit_val, self.fit_arg, self.ncell = fit_val, fit_arg, ncell
+        self._host = None
+
+    def __len__(self):
+        return self.ncell
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += self.ncell
+        if not 0 <= i < self.ncell:
+            raise IndexError('row index out of range')
+        if self._host is None:
+            self._host = (_np(self.fit_val), _np(self.fit_arg))
+        off = i * (i + 1) // 2
+        return np.stack([self._host[0][off:off + i + 1], self._host[1][off:off + i + 1]])
+
+    def __iter__(self):
+        for i in range(self.ncell):
+            yield self[i]
+
+
+class PhaseCellsLogLikelihood(CellsLogLikelihood):
+    """Bayesian Blocks on a folded light curve: profiles and cells wrapped once
+    on either side (reference core.py:1392-1408)."""
+
+    def __init__(self, cells, device=None):
+        super(PhaseCellsLogLikelihood, self).__init__(cells, device=device)
+        b = self.cells
+        self._orig_cells = b
+        rep = lambda x: torch.cat([x, x, x]).contiguous()
+        self._dom_d, self._cod_d = rep(self._dom_d), rep(self._cod_d)
+        self._dom_h = self._cod_h = None
+        self.cells = CellBatch(b.we, b.ti, rep(b.lo), rep(b.hi),
+                               torch.cat([b.starts - 1, b.starts, b.starts + 1]).contiguous(),
+                               torch.cat([b.stops - 1, b.stops, b.stops + 1]).contiguous(),
+                               rep(b.sexp), rep(b.bexp))
+        self._cr = self.cells.ranges()
+        self.profile_background = False
 
 
 class CellsLogLikelihoodOld(object):

@@ -1,0 +1,243 @@
+// Bayesian Blocks on the cached likelihood profiles (gfx950).
+//
+// The reference (core.py:1108-1208) builds, for every cell i, the fitness of
+// every block that ends with cell i: it sums the log profiles of the cells of
+// the block, each interpolated (numpy.interp, -inf outside the support) onto
+// a 1000-point grid over the support of cell i, and takes the maximum.  That
+// is O(ncell^2 / 2) interpolations of 1000 points, sequential in the block
+// start for one i but independent between the i's.
+//
+// Here one workgroup owns one i ("row").  Its 256 threads hold the 1000 grid
+// points and their running sums in registers (four points per thread) and
+// walk back over the cells; the maximum over the grid is reduced inside each
+// wavefront per cell and across the four wavefronts once per 32 cells.
+// Rows are scheduled longest first.  The slopes numpy.interp divides for are
+// formed once per cell by a kernel of their own, with the same IEEE division,
+// so the interpolated values are the reference's to the last bit (this file
+// is compiled without FMA contraction: numpy multiplies, rounds, then adds).
+// The dynamic programme over the rows (core.py:1146-1161) runs in a single
+// workgroup: it is sequential in i, with a parallel arg-max inside each step.
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int BB_THREADS = 256;
+constexpr int BB_PPT = 4;                       // grid points per thread
+constexpr int BB_MAX_GRID = BB_THREADS * BB_PPT;
+constexpr int BB_RING = 32;                     // cells between two cross-wavefront reductions
+
+// slopes[c][j] = (cod[c][j+1] - cod[c][j]) / (dom[c][j+1] - dom[c][j])  (numpy's arr_interp)
+__global__ void bb_slopes_kernel(const double *__restrict__ dom, const double *__restrict__ cod, int64_t ncell,
+                                 int npt, double *__restrict__ slopes)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncell * npt) return;
+    const int j = (int)(k % npt);
+    double s = 0.0;
+    if (j + 1 < npt) s = (cod[k + 1] - cod[k]) / (dom[k + 1] - dom[k]);
+    slopes[k] = s;
+}
+
+// numpy.linspace(a0, a1, n)[i]
+__device__ __forceinline__ double linspace_at(double a0, double a1, double step, int i, int n)
+{
+    if (i == n - 1 && n > 1) return a1;
+    return (double)i * step + a0;
+}
+
+// numpy.interp(x, xp, fp, left=-inf, right=-inf) for one x; xp is a uniform
+// grid (numpy.linspace), so the interval is guessed arithmetically and then
+// settled by the comparisons numpy's search makes.
+__device__ __forceinline__ double interp_one(double x, const double *__restrict__ xp,
+                                             const double *__restrict__ fp, const double *__restrict__ sl,
+                                             int npt, double x0, double xl, double inv_step)
+{
+    if (isnan(x)) return x;
+    if (x < x0 || x > xl) return -INFINITY;
+    if (x == xl) return fp[npt - 1];
+    int j = (int)((x - x0) * inv_step);
+    j = j < 0 ? 0 : (j > npt - 2 ? npt - 2 : j);
+    double xj = xp[j], xj1 = xp[j + 1];
+    while (j > 0 && x < xj) {
+        --j;
+        xj1 = xj;
+        xj = xp[j];
+    }
+    while (j < npt - 2 && x >= xj1) {
+        ++j;
+        xj = xj1;
+        xj1 = xp[j + 1];
+    }
+    const double fj = fp[j];
+    if (xj == x) return fj;
+    const double s = sl[j];
+    double r = s * (x - xj) + fj;
+    if (isnan(r)) {
+        const double fj1 = fp[j + 1];
+        r = s * (x - xj1) + fj1;
+        if (isnan(r) && fj == fj1) r = fj;
+    }
+    return r;
+}
+
+struct Best {
+    double v;      // maximum (NaN once a NaN was seen, as numpy.argmax treats NaN as the maximum)
+    int k;         // its first grid index
+};
+
+// order of numpy.argmax: a NaN beats everything, then the larger value, then the smaller index
+__device__ __forceinline__ Best best_of(Best a, Best b)
+{
+    const bool an = isnan(a.v), bn = isnan(b.v);
+    bool take_b;
+    if (an || bn) take_b = bn && (!an || b.k < a.k);
+    else take_b = (b.v > a.v) || (b.v == a.v && b.k < a.k);
+    return take_b ? b : a;
+}
+
+// Row i (cells 0 .. i): fit_val / fit_arg[i (i + 1) / 2 + j] = 2 * (max over the grid, alpha
+// there) of the summed profiles of cells j .. i  (core.py:1108-1136 with i0 = 0, i1 = i + 1).
+__global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__restrict__ dom,
+                                                                const double *__restrict__ cod,
+                                                                const double *__restrict__ slopes,
+                                                                int64_t ncell, int npt, int ngrid,
+                                                                double *__restrict__ fit_val,
+                                                                double *__restrict__ fit_arg)
+{
+    __shared__ double s_v[BB_RING][BB_THREADS / 64];
+    __shared__ int s_k[BB_RING][BB_THREADS / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t i = ncell - 1 - (int64_t)blockIdx.x;      // longest rows first
+    const double a0 = dom[i * npt], a1 = dom[i * npt + npt - 1];
+    const double gstep = ngrid > 1 ? (a1 - a0) / (double)(ngrid - 1) : 0.0;
+    double x[BB_PPT], acc[BB_PPT];
+#pragma unroll
+    for (int u = 0; u < BB_PPT; ++u) {
+        const int k = u * BB_THREADS + tid;
+        x[u] = linspace_at(a0, a1, gstep, k < ngrid ? k : ngrid - 1, ngrid);
+        acc[u] = 0.0;
+    }
+    const int64_t obase = i * (i + 1) / 2;
+    int pending = 0;
+    for (int64_t c = i; c >= 0; --c) {
+        const double *xp = dom + c * npt, *fp = cod + c * npt, *sl = slopes + c * npt;
+        const double x0 = xp[0], xl = xp[npt - 1];
+        const double inv_step = (double)(npt - 1) / (xl - x0);
+        Best b{-INFINITY, ngrid};
+#pragma unroll
+        for (int u = 0; u < BB_PPT; ++u) {
+            const int k = u * BB_THREADS + tid;
+            if (k < ngrid) {
+                acc[u] += interp_one(x[u], xp, fp, sl, npt, x0, xl, inv_step);
+                b = best_of(b, Best{acc[u], k});
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+            b = best_of(b, other);
+        }
+        const int slot = (int)((i - c) % BB_RING);
+        if (lane == 0) {
+            s_v[slot][wave] = b.v;
+            s_k[slot][wave] = b.k;
+        }
+        ++pending;
+        if (pending == BB_RING || c == 0) {
+            __syncthreads();
+            if (tid < pending) {
+                // slot tid belongs to cell c + (pending - 1 - tid)
+                Best r{s_v[tid][0], s_k[tid][0]};
+#pragma unroll
+                for (int w = 1; w < BB_THREADS / 64; ++w) r = best_of(r, Best{s_v[tid][w], s_k[tid][w]});
+                const int64_t cc = c + (pending - 1 - tid);
+                const int kk = r.k >= ngrid ? 0 : r.k;
+                fit_val[obase + cc] = r.v * 2;
+                fit_arg[obase + cc] = linspace_at(a0, a1, gstep, kk, ngrid) * 2;
+            }
+            __syncthreads();
+            pending = 0;
+        }
+    }
+}
+
+// best[0] = 0; best[i+1] = max over r <= i of (fit_val[row i][r] - prior) + best[r];
+// last[i] = the first r that attains it  (core.py:1146-1161).
+__global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__restrict__ fit_val, int64_t ncell,
+                                                            double prior, double *best, int64_t *last)
+{
+    __shared__ double s_v[16];
+    __shared__ int s_k[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) best[0] = 0.0;
+    __syncthreads();
+    for (int64_t i = 0; i < ncell; ++i) {
+        const double *row = fit_val + i * (i + 1) / 2;
+        Best b{-INFINITY, 0x7fffffff};
+        for (int64_t r = tid; r <= i; r += blockDim.x) {
+            const double a = (row[r] - prior) + best[r];
+            b = best_of(b, Best{a, (int)r});
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+            b = best_of(b, other);
+        }
+        if (lane == 0) {
+            s_v[wave] = b.v;
+            s_k[wave] = b.k;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Best r{s_v[0], s_k[0]};
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = best_of(r, Best{s_v[w], s_k[w]});
+            if (r.k == 0x7fffffff) r.k = 0;     // every candidate -inf: argmax of equal values is 0
+            best[i + 1] = r.v;
+            last[i] = r.k;
+        }
+        __syncthreads();
+    }
+}
+
+}   // namespace
+
+extern "C" size_t godot_bb_workspace_bytes(int64_t ncell, int npt)
+{
+    if (ncell < 0 || npt < 0) return 0;
+    return (size_t)ncell * (size_t)npt * sizeof(double);
+}
+
+extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt, int ngrid,
+                                void *workspace, double *fit_val, double *fit_arg, godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_bb_fitness: negative ncell");
+    GODOT_REQUIRE(npt >= 2, GODOT_E_INVALID, "godot_bb_fitness: npt must be at least 2");
+    GODOT_REQUIRE(ngrid >= 2 && ngrid <= BB_MAX_GRID, GODOT_E_UNSUPPORTED,
+                  "godot_bb_fitness: ngrid must be in [2, %d]", BB_MAX_GRID);
+    GODOT_REQUIRE(ncell < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_bb_fitness: too many cells");
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(dom && cod && workspace && fit_val && fit_arg, GODOT_E_INVALID,
+                  "godot_bb_fitness: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    double *slopes = (double *)workspace;
+    hipLaunchKernelGGL(bb_slopes_kernel, dim3((unsigned)ceil_div(ncell * npt, 256)), dim3(256), 0, st, dom, cod,
+                       ncell, npt, slopes);
+    hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)ncell), dim3(BB_THREADS), 0, st, dom, cod,
+                       (const double *)slopes, ncell, npt, ngrid, fit_val, fit_arg);
+    GODOT_LAUNCH_CHECK("godot_bb_fitness");
+    return GODOT_OK;
+}
+
+extern "C" int godot_bb_partition(const double *fit_val, int64_t ncell, double prior, double *best,
+                                  int64_t *last, godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_bb_partition: negative ncell");
+    GODOT_REQUIRE(ncell < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_bb_partition: too many cells");
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(fit_val && best && last, GODOT_E_INVALID, "godot_bb_partition: null argument");
+    hipLaunchKernelGGL(bb_partition_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, fit_val, ncell, prior,
+                       best, last);
+    GODOT_LAUNCH_CHECK("godot_bb_partition");
+    return GODOT_OK;
+}

@@ -382,3 +382,38 @@ def orbital_modulation_step(starts, stops, y, z, freq, rvals):
         _lib.call('godot_orbital_modulation_step', _p(starts), _p(stops), _p(y), _p(z), y.numel(),
                   float(freq), _p(means), _p(rvals), _p(ws), ws.numel(), _stream(dev))
     return means
+
+
+# ---------------------------------------------------------------------------
+# Bayesian Blocks
+# ---------------------------------------------------------------------------
+def bb_fitness(dom, cod, ngrid=1000):
+    """Fitness rows of every cell (packed lower triangle) -> (fit_val, fit_arg)."""
+    _dev_check(dom, F64, 'dom')
+    _dev_check(cod, F64, 'cod')
+    if dom.dim() != 2 or dom.shape != cod.shape:
+        raise ValueError('dom and cod must be [ncell, npt] arrays of one shape')
+    n, npt = dom.shape
+    dev = dom.device
+    ntri = n * (n + 1) // 2
+    fv = torch.empty(ntri, dtype=F64, device=dev)
+    fa = torch.empty(ntri, dtype=F64, device=dev)
+    ws = torch.empty(max(int(_lib.lib.godot_bb_workspace_bytes(n, npt)), 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_bb_fitness', _p(dom.contiguous()), _p(cod.contiguous()), n, int(npt), int(ngrid),
+                  _p(ws), _p(fv), _p(fa), _stream(dev))
+    return fv, fa
+
+
+def bb_partition(fit_val, ncell, prior):
+    """The dynamic programme over the fitness rows -> (best [ncell+1], last [ncell])."""
+    _dev_check(fit_val, F64, 'fit_val')
+    if fit_val.numel() != ncell * (ncell + 1) // 2:
+        raise ValueError('fit_val must hold ncell (ncell + 1) / 2 values')
+    dev = fit_val.device
+    best = torch.empty(ncell + 1, dtype=F64, device=dev)
+    last = torch.empty(ncell, dtype=I64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_bb_partition', _p(fit_val), int(ncell), float(prior), _p(best), _p(last), _stream(dev))
+    return best, last
+

@@ -304,6 +304,30 @@ int godot_z2m(const double *t, const double *w, int64_t nph,
               double *z2, double *h, void *workspace, size_t workspace_bytes,
               godot_stream_t stream);
 
+/* ---- Bayesian Blocks on the cached profiles ---------------------------------
+ * CellsLogLikelihood.fitness (core.py:1108-1136) for every row at once: with
+ * dom, cod the [ncell][npt] profiles of godot_cell_logpdf, row i (cells 0..i)
+ * holds, for every block start j <= i,
+ *   fit_val[i(i+1)/2 + j] = 2 max_k sum_{c=j..i} interp(grid_i[k]; dom[c], cod[c])
+ *   fit_arg[i(i+1)/2 + j] = 2 grid_i[argmax]
+ * where grid_i = linspace(dom[i][0], dom[i][npt-1], ngrid) and interp is
+ * numpy.interp with -inf outside a cell's support (the reference uses ngrid =
+ * 1000; ngrid <= 1024).  fitness(i0, i1) of the reference is entries i0..i1-1
+ * of row i1-1.  fit_val, fit_arg: ncell (ncell + 1) / 2 doubles each.
+ * workspace: godot_bb_workspace_bytes(ncell, npt).                            */
+size_t godot_bb_workspace_bytes(int64_t ncell, int npt);
+int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt,
+                     int ngrid, void *workspace, double *fit_val, double *fit_arg,
+                     godot_stream_t stream);
+
+/* The dynamic programme of do_bb / _do_bb_cache (core.py:1146-1161, 1184-1194):
+ *   best[0] = 0, best[i+1] = max_{r<=i} (fit_val[row i][r] - prior) + best[r],
+ *   last[i] = the first r attaining it.
+ * best: ncell + 1 doubles, last: ncell int64.  The walk back through `last`
+ * (core.py:1164-1169) is left to the host.                                    */
+int godot_bb_partition(const double *fit_val, int64_t ncell, double prior,
+                       double *best, int64_t *last, godot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
