@@ -544,7 +544,8 @@ class CellsLogLikelihood(object):
             k = last[k - 1]
         indices = np.append(0, np.asarray(cps, dtype=int)[::-1])
         var_dof = len(indices) - 1
-        var_ts = (best_fitness - rows[n - 1][0][0]) + prior * var_dof
+        whole = float(rows.fit_val[(n - 1) * n // 2].cpu())      # fitness of the single block 0 .. n-1
+        var_ts = (best_fitness - whole) + prior * var_dof
         return indices, best_fitness + len(indices) * prior, var_ts, var_dof, rows
 
     _do_bb_cache = do_bb

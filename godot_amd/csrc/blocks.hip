@@ -16,7 +16,7 @@
 // so the interpolated values are the reference's to the last bit (this file
 // is compiled without FMA contraction: numpy multiplies, rounds, then adds).
 // The dynamic programme over the rows (core.py:1146-1161) runs in a single
-// workgroup: it is sequential in i, with a parallel arg-max inside each step.
+// workgroup, 64 rows at a time (see bb_partition_kernel).
 
 #include "common.hpp"
 
@@ -164,37 +164,62 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
 
 // best[0] = 0; best[i+1] = max over r <= i of (fit_val[row i][r] - prior) + best[r];
 // last[i] = the first r that attains it  (core.py:1146-1161).
+// The recurrence is sequential in i, but row i needs best[r] of the current
+// stretch of 64 rows only for r inside the stretch: the candidates r below the
+// stretch are reduced for all its rows at once by the sixteen wavefronts, the
+// candidates inside it by one wavefront row after row without a barrier.
+constexpr int BP_K = 64;
+
 __global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__restrict__ fit_val, int64_t ncell,
                                                             double prior, double *best, int64_t *last)
 {
-    __shared__ double s_v[16];
-    __shared__ int s_k[16];
+    __shared__ double s_v[BP_K];
+    __shared__ int s_k[BP_K];
+    __shared__ double s_best[BP_K + 1];       // best[i0 .. i0 + 64] of the stretch
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) best[0] = 0.0;
     __syncthreads();
-    for (int64_t i = 0; i < ncell; ++i) {
-        const double *row = fit_val + i * (i + 1) / 2;
-        Best b{-INFINITY, 0x7fffffff};
-        for (int64_t r = tid; r <= i; r += blockDim.x) {
-            const double a = (row[r] - prior) + best[r];
-            b = best_of(b, Best{a, (int)r});
-        }
+    for (int64_t i0 = 0; i0 < ncell; i0 += BP_K) {
+        const int kmax = (int)((ncell - i0) < BP_K ? (ncell - i0) : BP_K);
+        // candidates below the stretch
+        for (int t = wave; t < kmax; t += 16) {
+            const int64_t i = i0 + t;
+            const double *row = fit_val + i * (i + 1) / 2;
+            Best b{-INFINITY, 0x7fffffff};
+            for (int64_t r = lane; r < i0; r += 64) b = best_of(b, Best{(row[r] - prior) + best[r], (int)r});
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
-            b = best_of(b, other);
+            for (int o = 1; o < 64; o <<= 1) {
+                Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+                b = best_of(b, other);
+            }
+            if (lane == 0) {
+                s_v[t] = b.v;
+                s_k[t] = b.k;
+            }
         }
-        if (lane == 0) {
-            s_v[wave] = b.v;
-            s_k[wave] = b.k;
-        }
+        if (tid == 0) s_best[0] = best[i0];
         __syncthreads();
-        if (tid == 0) {
-            Best r{s_v[0], s_k[0]};
-            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = best_of(r, Best{s_v[w], s_k[w]});
-            if (r.k == 0x7fffffff) r.k = 0;     // every candidate -inf: argmax of equal values is 0
-            best[i + 1] = r.v;
-            last[i] = r.k;
+        // candidates inside the stretch: one wavefront, row after row
+        if (wave == 0) {
+            for (int t = 0; t < kmax; ++t) {
+                const int64_t i = i0 + t;
+                const double *row = fit_val + i * (i + 1) / 2;
+                Best b{s_v[t], s_k[t]};
+                if (lane <= t) b = best_of(b, Best{(row[i0 + lane] - prior) + s_best[lane], (int)(i0 + lane)});
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+                    b = best_of(b, other);
+                }
+                if (b.k == 0x7fffffff) b.k = 0;
+                if (lane == 0) {
+                    s_best[t + 1] = b.v;
+                    best[i + 1] = b.v;
+                    last[i] = b.k;
+                }
+                // the wavefront's own LDS accesses stay in program order
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         }
         __syncthreads();
     }
