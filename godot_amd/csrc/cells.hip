@@ -556,7 +556,10 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     int gl, gr;
-    if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
+    if (godot_detail::block_cells(nph, ncell)) {
+        godot_detail::fit_block_launch(we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap, alpha, ts,
+                                       flags, st);
+    } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
         // sparse cells: groups of one to four lanes per cell (cells_group.hip)
         godot_detail::fit_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap,
                                        alpha, ts, flags, st);
@@ -632,7 +635,10 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     int gl, gr;
-    if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
+    if (godot_detail::block_cells(nph, ncell)) {
+        godot_detail::logpdf_block_launch(we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero, swap, dom,
+                                          cod, flags, st);
+    } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
         // sparse cells: groups of one to four lanes per cell (cells_group.hip)
         godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
                                           swap, dom, cod, flags, st);

@@ -11,6 +11,14 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
                       const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
                       const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
                       hipStream_t st);
+// very large cells, one workgroup each (cells_block.hip)
+bool block_cells(int64_t nph, int64_t ncell);
+void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
+                      const double *B, int64_t ncell, const double *guess, double guess0, const double *beta,
+                      double beta0, int swap, double *alpha, double *ts, int32_t *flags, hipStream_t st);
+void logpdf_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
+                         const double *B, int64_t ncell, const double *aopt, double dlogl, int npt,
+                         int include_zero, int swap, double *dom, double *cod, int32_t *flags, hipStream_t st);
 void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                          const double *S, const double *B, int64_t ncell, const double *aopt, double dlogl,
                          int npt, int include_zero, int swap, double *dom, double *cod, int32_t *flags,

@@ -304,6 +304,61 @@ def test_logpdf_sparse_cell_kernels(mean, variant):
     assert ncmp > 60
 
 
+@pytest.mark.parametrize('variant', ['plain', 'swap', 'beta', 'guess', 'npt300', 'given'])
+def test_very_large_cells(variant):
+    """Cells of tens of thousands of photons (what merged Bayesian blocks are):
+    one workgroup per cell; fit, TS and profile grid against the oracle."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(len(variant) + 31)
+    cnt = np.array([20000, 70001, 33000, 17003], dtype=np.int64)
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = cnt * 0.17 * np.array([1.0, 0.4, 2.5, 40.0])
+    B = S * 5
+    wd, od = torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev)
+    Sd, Bd = torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev)
+    kw, gkw = {}, {}
+    guess, beta = 1.0, 1.0
+    if variant == 'swap':
+        cr = ops.CellRanges.from_offsets(1 - wd, od, Bd, Sd)
+        kw['swap'] = gkw['swap'] = True
+    else:
+        cr = ops.CellRanges.from_offsets(wd, od, Sd, Bd)
+    if variant == 'beta':
+        beta = kw['beta'] = 1.6
+    if variant == 'guess':
+        guess = kw['guess'] = 0.3
+    npt = 300 if variant == 'npt300' else 100
+    given = None
+    if variant == 'given':
+        given = np.array([0.9, 2.3, 0.0, 0.05])
+        gkw['aopt'] = torch.from_numpy(given).to(dev)
+    alpha, ts, flags = ops.cell_fit(cr, **kw)
+    dom, cod, gfl = ops.cell_logpdf(cr, dlogl=20, npt=npt, **gkw)
+    alpha, ts, dom, cod = alpha.cpu().numpy(), ts.cpu().numpy(), dom.cpu().numpy(), cod.cpu().numpy()
+    tol = RTOL * (100 if variant == 'swap' else 1)
+    with np.errstate(all='ignore'):
+        for c in range(len(cnt)):
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            a = cl.get_max(guess=guess, beta=beta)
+            t = cl.get_ts(a)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            assert abs(alpha[c] - a) <= tol * max(1, abs(a)), (c, alpha[c], a)
+            assert abs(ts[c] - t) <= tol * max(sc, abs(t)), (c, ts[c], t)
+            try:
+                d, v = cl.get_logpdf(aopt=None if given is None else given[c], dlogl=20, npt=npt)
+            except RuntimeError:
+                # a centre far from the maximum: the reference re-centres without end
+                assert gfl[c].item() & 0x10 and np.isnan(dom[c]).all()
+                continue
+            if np.isnan(d).any() or np.isnan(v).any():
+                continue
+            assert np.abs(dom[c] - d).max() <= tol * max(1.0, np.abs(d).max()), c
+            assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), c
+
+
 def test_joint_fit_meets_reference_likelihood(golden):
     """get_max(profile_background=True): the reference's optimiser (scipy TNC,
     ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
