@@ -231,6 +231,32 @@ def main():
         extra['power_spectrum_fft'] = dict(ms=f_ms, nbins=nb, l=l)
         torch.cuda.empty_cache()
 
+        # Bayesian Blocks at the C1 shape: ten years of daily cells from the same photons
+        bcells = data.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+        bcll = core.CellsLogLikelihood(bcells)
+        bcll.do_bb(prior=8)
+        torch.cuda.synchronize()
+        tb = []
+        for _ in range(3):
+            bcll.fitness_vals = None
+            t0b = time.perf_counter()
+            bcll._fitness_rows()
+            torch.cuda.synchronize()
+            t1b = time.perf_counter()
+            bb = bcll.do_bb(prior=8)
+            torch.cuda.synchronize()
+            t2b = time.perf_counter()
+            bcll.get_bb_lightcurve(bb_prior=8)
+            torch.cuda.synchronize()
+            tb.append((t1b - t0b, t2b - t1b, time.perf_counter() - t2b))
+        tb = np.min(np.array(tb), axis=0)
+        nb = len(bcells)
+        extra['bayesian_blocks'] = dict(ncell=nb, fitness_rows_ms=tb[0] * 1e3, partition_ms=tb[1] * 1e3,
+                                        block_lightcurve_ms=tb[2] * 1e3, blocks=int(len(bb[0])),
+                                        interpolations_per_s=1000.0 * nb * (nb + 1) / 2 / tb[0])
+        del bcll
+        torch.cuda.empty_cache()
+
     cpu = None
     if world == 1 and not args.no_cpu:
         cpu = cpu_baseline(s, args.tcell, args.cpu_seconds)

@@ -102,13 +102,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
                                                                 const double *__restrict__ cod,
                                                                 const double *__restrict__ slopes,
                                                                 int64_t ncell, int npt, int ngrid,
+                                                                int64_t row_begin, int64_t row_end,
                                                                 double *__restrict__ fit_val,
                                                                 double *__restrict__ fit_arg)
 {
     __shared__ double s_v[BB_RING][BB_THREADS / 64];
     __shared__ int s_k[BB_RING][BB_THREADS / 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t i = ncell - 1 - (int64_t)blockIdx.x;      // longest rows first
+    const int64_t i = row_end - 1 - (int64_t)blockIdx.x;    // longest rows first
     const double a0 = dom[i * npt], a1 = dom[i * npt + npt - 1];
     const double gstep = ngrid > 1 ? (a1 - a0) / (double)(ngrid - 1) : 0.0;
     double x[BB_PPT], acc[BB_PPT];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
         x[u] = linspace_at(a0, a1, gstep, k < ngrid ? k : ngrid - 1, ngrid);
         acc[u] = 0.0;
     }
-    const int64_t obase = i * (i + 1) / 2;
+    const int64_t obase = i * (i + 1) / 2 - row_begin * (row_begin + 1) / 2;
     int pending = 0;
     for (int64_t c = i; c >= 0; --c) {
         const double *xp = dom + c * npt, *fp = cod + c * npt, *sl = slopes + c * npt;
@@ -234,22 +235,25 @@ extern "C" size_t godot_bb_workspace_bytes(int64_t ncell, int npt)
 }
 
 extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt, int ngrid,
-                                void *workspace, double *fit_val, double *fit_arg, godot_stream_t stream)
+                                int64_t row_begin, int64_t row_end, void *workspace, double *fit_val,
+                                double *fit_arg, godot_stream_t stream)
 {
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_bb_fitness: negative ncell");
     GODOT_REQUIRE(npt >= 2, GODOT_E_INVALID, "godot_bb_fitness: npt must be at least 2");
     GODOT_REQUIRE(ngrid >= 2 && ngrid <= BB_MAX_GRID, GODOT_E_UNSUPPORTED,
                   "godot_bb_fitness: ngrid must be in [2, %d]", BB_MAX_GRID);
     GODOT_REQUIRE(ncell < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_bb_fitness: too many cells");
-    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= ncell, GODOT_E_INVALID,
+                  "godot_bb_fitness: rows must satisfy 0 <= row_begin <= row_end <= ncell");
+    if (row_begin == row_end) return GODOT_OK;
     GODOT_REQUIRE(dom && cod && workspace && fit_val && fit_arg, GODOT_E_INVALID,
                   "godot_bb_fitness: null argument");
     hipStream_t st = (hipStream_t)stream;
     double *slopes = (double *)workspace;
     hipLaunchKernelGGL(bb_slopes_kernel, dim3((unsigned)ceil_div(ncell * npt, 256)), dim3(256), 0, st, dom, cod,
                        ncell, npt, slopes);
-    hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)ncell), dim3(BB_THREADS), 0, st, dom, cod,
-                       (const double *)slopes, ncell, npt, ngrid, fit_val, fit_arg);
+    hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)(row_end - row_begin)), dim3(BB_THREADS), 0, st, dom,
+                       cod, (const double *)slopes, ncell, npt, ngrid, row_begin, row_end, fit_val, fit_arg);
     GODOT_LAUNCH_CHECK("godot_bb_fitness");
     return GODOT_OK;
 }

@@ -6,7 +6,9 @@ The path shards without any data-path exchange:
     count; every rank reads only its slice of the photon array;
   * Z^2_m searches: contiguous ranges of trial-frequency indices; the photon
     list is replicated (16 MB for 1e6 photons);
-  * multi-source batches: sources dealt round-robin.
+  * multi-source batches: sources dealt round-robin;
+  * Bayesian-Blocks fitness rows: contiguous row ranges balanced by row length
+    (row i costs i + 1 cell profiles); the profiles are replicated.
 The only collectives are result collection: an all-gather of fixed-width
 per-cell records (padded to the largest shard) and, for searches, an
 all-reduce(max) / all-gather of per-rank maxima.  Both are latency-bound
@@ -124,3 +126,34 @@ def search_sharded(nf, search_fn, gather_spectrum=False, group=None):
         sizes = [frequency_shard(nf, r, world)[1] for r in range(world)]
         spec = all_gather_ragged(z, sizes=sizes, group=group)
     return float(best[0].cpu()), int(best[1].cpu()), spec
+
+
+def bb_row_shard(ncell, rank=None, world=None, group=None):
+    """(first_row, last_row_exclusive) of this rank's share of the fitness rows:
+    row i sums i + 1 profiles, so the ranges are balanced by sum(i + 1)."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    i = np.arange(ncell + 1, dtype=np.int64)
+    b = split_by_weight(i * (i + 1) // 2, world)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def bb_fitness_sharded(ncell, rows_fn, group=None):
+    """Compute this rank's fitness rows and return the packed lower triangle of
+    ALL rows on every rank.
+
+    rows_fn : callable(first_row, last_row) -> (fit_val, fit_arg) tensors holding
+              those rows packed one after the other (ops.bb_fitness(..., rows=...))
+    """
+    rank, world = _world(group)
+    r0, r1 = bb_row_shard(ncell, group=group)
+    fv, fa = rows_fn(r0, r1)
+    tri = lambda r: r * (r + 1) // 2
+    if fv.numel() != tri(r1) - tri(r0):
+        raise ValueError('rows_fn returned %d values for rows %d..%d' % (fv.numel(), r0, r1))
+    sizes = [tri(bb_row_shard(ncell, r, world)[1]) - tri(bb_row_shard(ncell, r, world)[0])
+             for r in range(world)]
+    rec = all_gather_ragged(torch.stack([fv, fa], dim=1), sizes=sizes, group=group)
+    return rec[:, 0].contiguous(), rec[:, 1].contiguous()
+

@@ -387,21 +387,26 @@ def orbital_modulation_step(starts, stops, y, z, freq, rvals):
 # ---------------------------------------------------------------------------
 # Bayesian Blocks
 # ---------------------------------------------------------------------------
-def bb_fitness(dom, cod, ngrid=1000):
-    """Fitness rows of every cell (packed lower triangle) -> (fit_val, fit_arg)."""
+def bb_fitness(dom, cod, ngrid=1000, rows=None):
+    """Fitness rows (packed lower triangle) -> (fit_val, fit_arg).  rows = (first,
+    last_exclusive) restricts the work to those rows; the result then holds
+    only them, packed one after the other."""
     _dev_check(dom, F64, 'dom')
     _dev_check(cod, F64, 'cod')
     if dom.dim() != 2 or dom.shape != cod.shape:
         raise ValueError('dom and cod must be [ncell, npt] arrays of one shape')
     n, npt = dom.shape
+    r0, r1 = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    if not 0 <= r0 <= r1 <= n:
+        raise ValueError('rows must satisfy 0 <= first <= last <= ncell')
     dev = dom.device
-    ntri = n * (n + 1) // 2
+    ntri = r1 * (r1 + 1) // 2 - r0 * (r0 + 1) // 2
     fv = torch.empty(ntri, dtype=F64, device=dev)
     fa = torch.empty(ntri, dtype=F64, device=dev)
     ws = torch.empty(max(int(_lib.lib.godot_bb_workspace_bytes(n, npt)), 8), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.call('godot_bb_fitness', _p(dom.contiguous()), _p(cod.contiguous()), n, int(npt), int(ngrid),
-                  _p(ws), _p(fv), _p(fa), _stream(dev))
+                  r0, r1, _p(ws), _p(fv), _p(fa), _stream(dev))
     return fv, fa
 
 

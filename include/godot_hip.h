@@ -313,12 +313,15 @@ int godot_z2m(const double *t, const double *w, int64_t nph,
  * where grid_i = linspace(dom[i][0], dom[i][npt-1], ngrid) and interp is
  * numpy.interp with -inf outside a cell's support (the reference uses ngrid =
  * 1000; ngrid <= 1024).  fitness(i0, i1) of the reference is entries i0..i1-1
- * of row i1-1.  fit_val, fit_arg: ncell (ncell + 1) / 2 doubles each.
+ * of row i1-1.  Rows row_begin .. row_end-1 are computed (0, ncell for all:
+ * the rows are independent, which is how the work is split over GPUs); the
+ * outputs hold those rows packed one after the other, i.e. the entry above
+ * sits at i(i+1)/2 - row_begin(row_begin+1)/2 + j.
  * workspace: godot_bb_workspace_bytes(ncell, npt).                            */
 size_t godot_bb_workspace_bytes(int64_t ncell, int npt);
 int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt,
-                     int ngrid, void *workspace, double *fit_val, double *fit_arg,
-                     godot_stream_t stream);
+                     int ngrid, int64_t row_begin, int64_t row_end, void *workspace,
+                     double *fit_val, double *fit_arg, godot_stream_t stream);
 
 /* The dynamic programme of do_bb / _do_bb_cache (core.py:1146-1161, 1184-1194):
  *   best[0] = 0, best[i+1] = max_{r<=i} (fit_val[row i][r] - prior) + best[r],

@@ -63,7 +63,22 @@ def _worker(rank, world, port, q):
         full = orc.z2m(t, w, 1e-3, 2e-7, nf, m=2)
         ok2 = (jmax == int(np.argmax(full))) and (zmax == full.max()) and \
             np.array_equal(spec.numpy(), full)
-        q.put((rank, ok1, ok2, (c0, c1), gd.source_shard(7)))
+        # Bayesian-Blocks fitness rows, sharded by row
+        nb, npt = 23, 16
+        lo = rng.uniform(0, 2, nb)
+        dom = np.linspace(lo, lo + rng.uniform(0.5, 3, nb), npt).T.copy()
+        cod = -((dom - dom.mean(axis=1, keepdims=True)) * 2) ** 2
+
+        def rows_fn(r0, r1):
+            with np.errstate(all='ignore'):
+                rows = [orc.bb_fitness(dom, cod, 0, i + 1) for i in range(r0, r1)]
+            cat = lambda k: np.concatenate([r[k] for r in rows]) if rows else np.empty(0)
+            return torch.from_numpy(cat(0)), torch.from_numpy(cat(1))
+
+        fv, fa = gd.bb_fitness_sharded(nb, rows_fn)
+        rv, ra = rows_fn(0, nb)
+        ok3 = bool(torch.equal(fv, rv)) and bool(torch.equal(fa, ra))
+        q.put((rank, ok1, ok2 and ok3, (c0, c1), gd.source_shard(7)))
     finally:
         dist.destroy_process_group()
 
@@ -105,3 +120,9 @@ def test_shard_helpers_single_process():
     assert gd.frequency_shard(2, 3, 4) == (2, 0)
     b = gd.split_by_weight(np.array([0, 10, 20, 30, 40]), 2)
     assert list(b) == [0, 2, 4]
+    # fitness rows: contiguous cover, work (sum of row lengths) within a row of equal
+    edges = [gd.bb_row_shard(1000, r, 4) for r in range(4)]
+    assert edges[0][0] == 0 and edges[-1][1] == 1000
+    assert all(edges[r][1] == edges[r + 1][0] for r in range(3))
+    work = [sum(range(a + 1, b + 1)) for a, b in edges]
+    assert max(work) - min(work) <= 2 * 1000

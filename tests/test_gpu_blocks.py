@@ -111,3 +111,18 @@ def test_fitness_matches_oracle_on_random_profiles():
         assert np.array_equal(fv[clean], rv[clean])
         assert np.array_equal(fa[clean], ra[clean])
         assert np.isnan(fv[~clean]).all()
+
+
+def test_fitness_row_ranges_tile_the_triangle(golden):
+    """Rows computed in ranges (the multi-GPU split) concatenate to the whole."""
+    from godot_amd import ops, dist as gd
+    g = golden('bayesian_blocks.npz')
+    dom, cod = _d(g['dom']), _d(g['cod'])
+    n = dom.shape[0]
+    parts = [ops.bb_fitness(dom, cod, rows=gd.bb_row_shard(n, r, 3)) for r in range(3)]
+    fv = torch.cat([p[0] for p in parts]).cpu().numpy()
+    fa = torch.cat([p[1] for p in parts]).cpu().numpy()
+    assert np.array_equal(fv, g['fit_val']) and np.array_equal(fa, g['fit_arg'])
+    e = ops.bb_fitness(dom, cod, rows=(7, 7))
+    assert e[0].numel() == 0
+
