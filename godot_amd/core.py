@@ -718,6 +718,12 @@ class Data(object):
         self._exposure_table = None
         self._t0 = float(self.TSTART[0].cpu())
         self._t1 = float(self.TSTOP[-1].cpu())
+        # per-row scaled exposures while scalers are applied (reference core.py:2282-2316)
+        self.sexposure = None
+        self.bexposure = None
+        self._scaled_tables = {}
+        self._scaled_key = None
+        self._ft2_host = None
 
     def _vprint(self, s, level):
         if self._verbosity >= level:
@@ -726,6 +732,17 @@ class Data(object):
     def get_exposure(self, times, deadtime_too=False, cumulative=True):
         """(exp, sexp, bexp, dead) at / between the given times."""
         t = _to_dev(times, self.device)
+        if self.sexposure is not None:
+            # scalers applied: running sums over the rescaled rows, kept per scaler pair
+            tab = self._scaled_tables.get(self._scaled_key)
+            if tab is None:
+                tab = ops.exposure_table_rows(self.TSTART, self.TSTOP, self.exposure, self.sexposure,
+                                              self.bexposure, self.LIVETIME)
+                if self._scaled_key is not None:
+                    self._scaled_tables[self._scaled_key] = tab
+            return ops.exposure_at_rows(self.TSTART, self.TSTOP, self.exposure, self.sexposure,
+                                        self.bexposure, self.LIVETIME, tab, t, cumulative=cumulative,
+                                        deadtime_too=deadtime_too)
         if self._exposure_table is None:
             # running sums of the exposure table: built once, reused by every query
             self._exposure_table = ops.exposure_table(
@@ -735,6 +752,103 @@ class Data(object):
                                self.S / self.E, self.B / self.E, self._exposure_table, t,
                                cumulative=cumulative, deadtime_too=deadtime_too)
 
+    def _ft2(self):
+        if self._ft2_host is None:
+            self._ft2_host = (_np(self.TSTART), _np(self.TSTOP))
+        return self._ft2_host
+
+    def apply_scalers(self, src_scaler=None, bkg_scaler=None):
+        """Rescale the rows' source / background exposures and the photon weights
+        (reference core.py:2282-2306).  Returns what revert_scalers needs."""
+        if (src_scaler is None) and (bkg_scaler is None):
+            return None
+        original = (self.we, self.sexposure, self.bexposure, self._scaled_key)
+        key = (id(src_scaler), id(bkg_scaler))
+        cached = self._scaled_tables.get(('rows',) + key)
+        if cached is None:
+            T0, T1 = self._ft2()
+            sexp = self.exposure * (self.S / self.E)
+            bexp = self.exposure * (self.B / self.E)
+            if src_scaler is not None:
+                sexp = sexp * _to_dev(src_scaler(T0, T1), self.device)
+            if bkg_scaler is not None:
+                bexp = bexp * _to_dev(bkg_scaler(T0, T1), self.device)
+            sscl = src_scaler(self.ti) if src_scaler is not None else 1.0
+            bscl = bkg_scaler(self.ti) if bkg_scaler is not None else 1.0
+            we = ops.rescale_weights(self.we, _to_dev(sscl, self.device) if not np.isscalar(sscl) else sscl,
+                                     _to_dev(bscl, self.device) if not np.isscalar(bscl) else bscl)
+            # the scaler objects are kept alive with their tables so that ids stay unique
+            cached = (sexp.contiguous(), bexp.contiguous(), we, src_scaler, bkg_scaler)
+            self._scaled_tables[('rows',) + key] = cached
+        self.sexposure, self.bexposure, self.we = cached[0], cached[1], cached[2]
+        self._scaled_key = key
+        return original
+
+    def revert_scalers(self, original_values):
+        if original_values is None:
+            return
+        self.we, self.sexposure, self.bexposure, self._scaled_key = original_values
+
+    def get_contiguous_exposures(self, tstart=None, tstop=None, max_interval=10):
+        """Start / stop times of the stretches of uninterrupted exposure
+        (reference core.py:1849-1860, py_exposure_p8.py:34-86); host arithmetic
+        on the exposure table."""
+        t0s, t1s = self._ft2()
+        if tstart is not None:
+            i = np.searchsorted(t1s, tstart)
+            t0s, t1s = t0s[i:].copy(), t1s[i:].copy()
+            if not (tstart < t0s[0]):
+                t0s[0] = tstart
+        if tstop is not None:
+            i = np.searchsorted(t1s, tstop)
+            t0s, t1s = t0s[:i].copy(), t1s[:i].copy()
+            if tstop < t0s[-1]:
+                t0s, t1s = t0s[:-1], t1s[:-1]
+            else:
+                t1s[-1] = tstop
+        gap = (t0s[1:] - t1s[:-1]) > max_interval
+        starts = np.concatenate([[t0s[0]], t0s[1:][gap]])
+        stops = np.concatenate([t1s[:-1][gap], [t1s[-1]]])
+        return starts, stops
+
+    def get_cells_from_time_intervals(self, tstarts, tstops, randomize=False, seed=None):
+        """Cells for given start / stop times (reference core.py:2208-2270).  With
+        randomize the photons of the intervals are dealt out again in proportion
+        to the exposures, with new uniform times (numpy's default_rng stream,
+        generated on the host, so that the draw is the reference's)."""
+        tstarts_h = np.asarray(_np(tstarts), dtype=np.float64)
+        tstops_h = np.asarray(_np(tstops), dtype=np.float64)
+        dev = self.device
+        t0d, t1d = _to_dev(tstarts_h, dev), _to_dev(tstops_h, dev)
+        exp = self.get_exposure(t1d)[1] - self.get_exposure(t0d)[1]
+        lo = ops.search_sorted(self.ti, t0d)
+        hi = ops.search_sorted(self.ti, t1d)
+        bexp = exp * (self.B / self.S)          # Cell.SonB = S / B for every cell
+        if not randomize:
+            return CellBatch(self.we, self.ti, lo, hi, t0d, t1d, exp, bexp)
+        rng = np.random.default_rng(seed)
+        lo_h, hi_h = _np(lo), _np(hi)
+        nphot = int(np.sum(hi_h) - np.sum(lo_h))
+        ncell = len(tstarts_h)
+        src = np.concatenate([np.arange(a, b) for a, b in zip(lo_h, hi_h)] or [np.empty(0, np.int64)])
+        we = ops.gather(self.we, _to_dev(src.astype(np.int64), dev, I64))
+        cexp = np.cumsum(_np(exp))
+        cexp /= cexp[-1]
+        new_idx = ops.search_sorted(_to_dev(cexp, dev), _to_dev(rng.random(nphot), dev))
+        order = torch.sort(new_idx, stable=True)[1]
+        new_idx = new_idx[order]
+        we = we[order].contiguous()
+        dts = (t1d - t0d)[new_idx]
+        ti = t0d[new_idx] + _to_dev(rng.random(nphot), dev) * dts
+        counts = torch.bincount(new_idx, minlength=ncell)
+        off = torch.cat([torch.zeros(1, dtype=I64, device=dev), torch.cumsum(counts, 0)])
+        return CellBatch(we, ti.contiguous(), off[:-1].contiguous(), off[1:].contiguous(), t0d, t1d, exp, bexp)
+
+    def get_contiguous_exposure_cells(self, tstart=None, tstop=None, randomize=False, seed=None):
+        """One cell per stretch of uninterrupted exposure (reference core.py:2272-2280)."""
+        starts, stops = self.get_contiguous_exposures(tstart=tstart, tstop=tstop)
+        return self.get_cells_from_time_intervals(starts, stops, randomize=randomize, seed=seed)
+
     def get_cells(self, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True,
                   time_series_only=False, use_barycenter=True, randomize=False, seed=None,
                   src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
@@ -743,9 +857,6 @@ class Data(object):
             raise NotImplementedError(
                 'use_barycenter=True needs the astropy ephemeris of the reference\'s bary '
                 'module, which this package does not carry; pass use_barycenter=False')
-        if randomize or (src_injector is not None) or (src_scaler is not None) \
-                or (bkg_scaler is not None):
-            raise NotImplementedError('randomize / scalers / injector are not built yet')
         if tcell is None:
             raise NotImplementedError('photon-based cells (tcell=None) are not built')
         if tstart is None:
@@ -774,6 +885,16 @@ class Data(object):
         edges = torch.from_numpy(edges_h).to(self.device)
         self._topo_edges = edges_h.copy()
 
+        # apply scales if provided (reverted before returning, as the reference does)
+        ov = self.apply_scalers(src_scaler=src_scaler, bkg_scaler=bkg_scaler)
+        try:
+            return self._cells_on_edges(edges, edges_h, trim_zero_exposure, time_series_only, randomize,
+                                        seed, src_injector, minimum_fractional_exposure)
+        finally:
+            self.revert_scalers(ov)
+
+    def _cells_on_edges(self, edges, edges_h, trim_zero_exposure, time_series_only, randomize, seed,
+                        src_injector, minimum_fractional_exposure):
         exp, sexp, bexp, dead = self.get_exposure(edges, deadtime_too=True, cumulative=False)
         starts, stops = edges[:-1].contiguous(), edges[1:].contiguous()
 
@@ -793,11 +914,47 @@ class Data(object):
             dead = ops.gather(dead, keep)
             lo, hi, counts = ops.gather(lo, keep), ops.gather(hi, keep), ops.gather(counts, keep)
 
+        we, ti = self.we, self.ti
+        if src_injector is not None:
+            randomize = True
+        if randomize:
+            # Deal the photons out again following the (possibly rescaled) source and
+            # background exposures (reference core.py:2129-2156).  The two uniform draws
+            # come from numpy's default_rng on the host so that they are the reference's;
+            # inside a cell the photons keep their time order (numpy's unstable argsort
+            # leaves them in another order: sums over a cell agree to rounding).
+            dev = self.device
+            n_all = int(counts.sum().cpu())
+            src = torch.repeat_interleave(lo - torch.cumsum(counts, 0) + counts, counts) + \
+                torch.arange(n_all, dtype=I64, device=dev)
+            weights = ops.gather(we, src)
+            times = ops.gather(ti, src)
+            sexp_h, bexp_h = _np(sexp), _np(bexp)
+            if src_injector is not None:
+                csexp = np.cumsum(src_injector(edges_h[:-1], edges_h[1:]) * sexp_h)
+            else:
+                csexp = np.cumsum(sexp_h)
+            csexp *= 1. / csexp[-1]
+            cbexp = np.cumsum(bexp_h)
+            cbexp *= 1. / cbexp[-1]
+            rng = np.random.default_rng(seed)
+            is_bkg = _to_dev(rng.random(n_all), dev) >= weights
+            rv = _to_dev(rng.random(n_all), dev)
+            idx = torch.where(is_bkg, ops.search_sorted(_to_dev(cbexp, dev), rv),
+                              ops.search_sorted(_to_dev(csexp, dev), rv))
+            order = torch.sort(idx, stable=True)[1]
+            ti, we = times[order].contiguous(), weights[order].contiguous()
+            counts = torch.bincount(idx, minlength=starts.numel())
+            if bool((exp[counts > 0] <= 0).any().cpu()):
+                raise AssertionError('photons were dealt to cells without exposure')
+            off = torch.cat([torch.zeros(1, dtype=I64, device=dev), torch.cumsum(counts, 0)])
+            lo, hi = off[:-1].contiguous(), off[1:].contiguous()
+
         if time_series_only:
-            w1, w2 = ops.cell_moments(self.we, lo, hi)
+            w1, w2 = ops.cell_moments(we, lo, hi)
             return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
                                   timesys='topocentric', minimum_exposure=0)
-        return CellBatch(self.we, self.ti, lo, hi, starts, stops, sexp, bexp)
+        return CellBatch(we, ti, lo, hi, starts, stops, sexp, bexp)
 
 
 # ---------------------------------------------------------------------------

@@ -148,12 +148,16 @@ __device__ __forceinline__ int64_t upper_bound(const double *a, int64_t n, doubl
 struct ExposureLoad {
     const double *tstart, *tstop, *exposure, *livetime;
     double s_over_e, b_over_e;
+    // per-row source- and background-scaled exposures when the caller has rescaled
+    // them (apply_scalers, core.py:2282-2306); null: the plain (S/E), (B/E) multiples
+    const double *sexposure = nullptr, *bexposure = nullptr;
     __device__ Quad operator()(int64_t i) const
     {
         double e = exposure[i];
         // (S/E)*exposure, (B/E)*exposure: core.py:1821-1824
         // dead time (TSTOP-TSTART)-LIVETIME: core.py:1831
-        return Quad{e, __dmul_rn(s_over_e, e), __dmul_rn(b_over_e, e),
+        return Quad{e, sexposure ? sexposure[i] : __dmul_rn(s_over_e, e),
+                    bexposure ? bexposure[i] : __dmul_rn(b_over_e, e),
                     __dsub_rn(__dsub_rn(tstop[i], tstart[i]), livetime[i])};
     }
 };
@@ -337,6 +341,74 @@ __global__ void gather_kernel(const T *src, const int64_t *idx, int64_t n, T *ds
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// numpy.searchsorted(a, v, side): out[k] = first index with a[i] >= v[k] (left) or > v[k] (right)
+__global__ void search_sorted_kernel(const double *a, int64_t n, const double *v, int64_t nv, int right,
+                                     int64_t *out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nv) return;
+    out[k] = right ? upper_bound(a, n, v[k]) : lower_bound(a, n, v[k]);
+}
+
+// scales[searchsorted(stops, t)]: the value of a piecewise-constant function at event
+// times (PiecewiseScaler.__call__ with one argument, scalers.py:46-51)
+__global__ void piecewise_lookup_kernel(const double *stops, const double *scales, int64_t nseg,
+                                        const double *t, int64_t n, double *out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int64_t i = lower_bound(stops, nseg, t[k]);
+    out[k] = scales[i < nseg ? i : nseg - 1];
+}
+
+// w' = a w / (a w + b (1 - w))  (apply_scalers, core.py:2304); a, b per photon or one value
+__global__ void rescale_weights_kernel(const double *w, const double *a, double a0, const double *b,
+                                       double b0, int64_t n, double *out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double wk = w[k], ak = a ? a[k] : a0, bk = b ? b[k] : b0;
+    const double num = __dmul_rn(ak, wk);
+    out[k] = num / __dadd_rn(num, __dmul_rn(bk, __dsub_rn(1.0, wk)));
+}
+
+int exposure_table_impl(const ExposureLoad &ld, int64_t n_ft2, void *table, size_t table_bytes,
+                        godot_stream_t stream, const char *fn)
+{
+    GODOT_REQUIRE(n_ft2 > 0, GODOT_E_INVALID, "%s: n_ft2 must be positive", fn);
+    GODOT_REQUIRE(ld.tstart && ld.tstop && ld.exposure && ld.livetime, GODOT_E_INVALID,
+                  "%s: null table pointer", fn);
+    GODOT_REQUIRE(table && table_bytes >= align256(sizeof(Quad) * (size_t)n_ft2), GODOT_E_WORKSPACE,
+                  "%s: table smaller than godot_exposure_table_bytes(n_ft2)", fn);
+    hipLaunchKernelGGL(exposure_cumsum_kernel, dim3(1), dim3(SEQ_THREADS), 0, (hipStream_t)stream, ld, n_ft2,
+                       (Quad *)table);
+    GODOT_LAUNCH_CHECK(fn);
+    return GODOT_OK;
+}
+
+int exposure_at_impl(const ExposureLoad &ld, int64_t n_ft2, const void *table, const double *times, int64_t n_t,
+                     int cumulative, double *out_exp, double *out_sexp, double *out_bexp, double *out_dead,
+                     void *workspace, size_t workspace_bytes, godot_stream_t stream, const char *fn)
+{
+    GODOT_REQUIRE(n_ft2 > 0 && n_t >= 0, GODOT_E_INVALID, "%s: bad sizes", fn);
+    GODOT_REQUIRE(ld.tstart && ld.tstop && ld.exposure && ld.livetime && table, GODOT_E_INVALID,
+                  "%s: null table pointer", fn);
+    if (n_t == 0) return GODOT_OK;
+    GODOT_REQUIRE(times && out_exp && out_sexp && out_bexp, GODOT_E_INVALID, "%s: null query/output pointer", fn);
+    GODOT_REQUIRE(workspace && workspace_bytes >= align256(sizeof(Quad) * (size_t)n_t), GODOT_E_WORKSPACE,
+                  "%s: workspace smaller than godot_exposure_workspace_bytes(n_t)", fn);
+    hipStream_t st = (hipStream_t)stream;
+    Quad *at = (Quad *)workspace;
+    hipLaunchKernelGGL(exposure_query_kernel, dim3((unsigned)ceil_div(n_t, 256)), dim3(256), 0, st, ld,
+                       (const Quad *)table, n_ft2, times, n_t, at);
+    int64_t n_out = cumulative ? n_t : n_t - 1;
+    if (n_out > 0)
+        hipLaunchKernelGGL(exposure_out_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st,
+                           (const Quad *)at, n_out, cumulative, out_exp, out_sexp, out_bexp, out_dead);
+    GODOT_LAUNCH_CHECK(fn);
+    return GODOT_OK;
+}
+
 }   // namespace
 
 extern "C" size_t godot_exposure_table_bytes(int64_t n_ft2)
@@ -349,16 +421,18 @@ extern "C" int godot_exposure_table(const double *tstart, const double *tstop, c
                                     double b_over_e, void *table, size_t table_bytes,
                                     godot_stream_t stream)
 {
-    GODOT_REQUIRE(n_ft2 > 0, GODOT_E_INVALID, "godot_exposure_table: n_ft2 must be positive");
-    GODOT_REQUIRE(tstart && tstop && exposure && livetime, GODOT_E_INVALID,
-                  "godot_exposure_table: null table pointer");
-    GODOT_REQUIRE(table && table_bytes >= godot_exposure_table_bytes(n_ft2), GODOT_E_WORKSPACE,
-                  "godot_exposure_table: table smaller than godot_exposure_table_bytes(n_ft2)");
     ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
-    hipLaunchKernelGGL(exposure_cumsum_kernel, dim3(1), dim3(SEQ_THREADS), 0, (hipStream_t)stream, ld, n_ft2,
-                       (Quad *)table);
-    GODOT_LAUNCH_CHECK("godot_exposure_table");
-    return GODOT_OK;
+    return exposure_table_impl(ld, n_ft2, table, table_bytes, stream, "godot_exposure_table");
+}
+
+extern "C" int godot_exposure_table_rows(const double *tstart, const double *tstop, const double *exposure,
+                                         const double *sexposure, const double *bexposure,
+                                         const double *livetime, int64_t n_ft2, void *table,
+                                         size_t table_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(sexposure && bexposure, GODOT_E_INVALID, "godot_exposure_table_rows: null scaled exposure");
+    ExposureLoad ld{tstart, tstop, exposure, livetime, 0.0, 0.0, sexposure, bexposure};
+    return exposure_table_impl(ld, n_ft2, table, table_bytes, stream, "godot_exposure_table_rows");
 }
 
 extern "C" size_t godot_exposure_workspace_bytes(int64_t n_t)
@@ -372,24 +446,57 @@ extern "C" int godot_exposure_at(const double *tstart, const double *tstop, cons
                                  double *out_exp, double *out_sexp, double *out_bexp, double *out_dead,
                                  void *workspace, size_t workspace_bytes, godot_stream_t stream)
 {
-    GODOT_REQUIRE(n_ft2 > 0 && n_t >= 0, GODOT_E_INVALID, "godot_exposure_at: bad sizes");
-    GODOT_REQUIRE(tstart && tstop && exposure && livetime && table, GODOT_E_INVALID,
-                  "godot_exposure_at: null table pointer");
-    if (n_t == 0) return GODOT_OK;
-    GODOT_REQUIRE(times && out_exp && out_sexp && out_bexp, GODOT_E_INVALID,
-                  "godot_exposure_at: null query/output pointer");
-    GODOT_REQUIRE(workspace && workspace_bytes >= godot_exposure_workspace_bytes(n_t), GODOT_E_WORKSPACE,
-                  "godot_exposure_at: workspace smaller than godot_exposure_workspace_bytes(n_t)");
-    hipStream_t st = (hipStream_t)stream;
-    Quad *at = (Quad *)workspace;
     ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
-    hipLaunchKernelGGL(exposure_query_kernel, dim3((unsigned)ceil_div(n_t, 256)), dim3(256), 0, st, ld,
-                       (const Quad *)table, n_ft2, times, n_t, at);
-    int64_t n_out = cumulative ? n_t : n_t - 1;
-    if (n_out > 0)
-        hipLaunchKernelGGL(exposure_out_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st,
-                           (const Quad *)at, n_out, cumulative, out_exp, out_sexp, out_bexp, out_dead);
-    GODOT_LAUNCH_CHECK("godot_exposure_at");
+    return exposure_at_impl(ld, n_ft2, table, times, n_t, cumulative, out_exp, out_sexp, out_bexp, out_dead,
+                            workspace, workspace_bytes, stream, "godot_exposure_at");
+}
+
+extern "C" int godot_exposure_at_rows(const double *tstart, const double *tstop, const double *exposure,
+                                      const double *sexposure, const double *bexposure,
+                                      const double *livetime, int64_t n_ft2, const void *table,
+                                      const double *times, int64_t n_t, int cumulative, double *out_exp,
+                                      double *out_sexp, double *out_bexp, double *out_dead, void *workspace,
+                                      size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(sexposure && bexposure, GODOT_E_INVALID, "godot_exposure_at_rows: null scaled exposure");
+    ExposureLoad ld{tstart, tstop, exposure, livetime, 0.0, 0.0, sexposure, bexposure};
+    return exposure_at_impl(ld, n_ft2, table, times, n_t, cumulative, out_exp, out_sexp, out_bexp, out_dead,
+                            workspace, workspace_bytes, stream, "godot_exposure_at_rows");
+}
+
+extern "C" int godot_search_sorted(const double *sorted, int64_t n, const double *values, int64_t nv,
+                                   int right, int64_t *out, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0 && nv >= 0, GODOT_E_INVALID, "godot_search_sorted: negative size");
+    if (nv == 0) return GODOT_OK;
+    GODOT_REQUIRE((sorted || n == 0) && values && out, GODOT_E_INVALID, "godot_search_sorted: null argument");
+    hipLaunchKernelGGL(search_sorted_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0,
+                       (hipStream_t)stream, sorted, n, values, nv, right, out);
+    GODOT_LAUNCH_CHECK("godot_search_sorted");
+    return GODOT_OK;
+}
+
+extern "C" int godot_piecewise_lookup(const double *stops, const double *scales, int64_t nseg,
+                                      const double *t, int64_t n, double *out, godot_stream_t stream)
+{
+    GODOT_REQUIRE(nseg > 0 && n >= 0, GODOT_E_INVALID, "godot_piecewise_lookup: bad sizes");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(stops && scales && t && out, GODOT_E_INVALID, "godot_piecewise_lookup: null argument");
+    hipLaunchKernelGGL(piecewise_lookup_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, stops, scales, nseg, t, n, out);
+    GODOT_LAUNCH_CHECK("godot_piecewise_lookup");
+    return GODOT_OK;
+}
+
+extern "C" int godot_rescale_weights(const double *w, const double *a, double a0, const double *b, double b0,
+                                     int64_t n, double *out, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_rescale_weights: negative size");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(w && out, GODOT_E_INVALID, "godot_rescale_weights: null argument");
+    hipLaunchKernelGGL(rescale_weights_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, a, a0, b, b0, n, out);
+    GODOT_LAUNCH_CHECK("godot_rescale_weights");
     return GODOT_OK;
 }
 

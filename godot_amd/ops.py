@@ -232,6 +232,73 @@ def exposure_at(tstart, tstop, exposure, livetime, s_over_e, b_over_e, table, ti
     return outs[0], outs[1], outs[2], (outs[3] if deadtime_too else None)
 
 
+def exposure_table_rows(tstart, tstop, exposure, sexposure, bexposure, livetime):
+    """Running sums when the scaled exposures are per-row arrays (apply_scalers)."""
+    n_ft2, dev = tstart.numel(), tstart.device
+    for t, nm in ((tstart, 'TSTART'), (tstop, 'TSTOP'), (exposure, 'exposure'), (sexposure, 'sexposure'),
+                  (bexposure, 'bexposure'), (livetime, 'LIVETIME')):
+        _dev_check(t, F64, nm)
+        if t.numel() != n_ft2:
+            raise ValueError('the exposure table columns must have equal lengths')
+    table = _workspace(_lib.lib.godot_exposure_table_bytes(n_ft2), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_exposure_table_rows', _p(tstart), _p(tstop), _p(exposure), _p(sexposure),
+                  _p(bexposure), _p(livetime), n_ft2, _p(table), table.numel(), _stream(dev))
+    return table
+
+
+def exposure_at_rows(tstart, tstop, exposure, sexposure, bexposure, livetime, table, times,
+                     cumulative=True, deadtime_too=True):
+    _dev_check(times, F64, 'times')
+    n_ft2, n_t, dev = tstart.numel(), times.numel(), times.device
+    n_out = n_t if cumulative else max(n_t - 1, 0)
+    outs = [torch.empty(n_out, dtype=F64, device=dev) for _ in range(4 if deadtime_too else 3)]
+    ws = _workspace(_lib.lib.godot_exposure_workspace_bytes(n_t), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_exposure_at_rows', _p(tstart), _p(tstop), _p(exposure), _p(sexposure),
+                  _p(bexposure), _p(livetime), n_ft2, _p(table), _p(times), n_t, int(bool(cumulative)),
+                  _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]) if deadtime_too else 0, _p(ws),
+                  ws.numel(), _stream(dev))
+    return outs[0], outs[1], outs[2], (outs[3] if deadtime_too else None)
+
+
+def search_sorted(sorted_vals, values, side='left'):
+    """numpy.searchsorted on the device -> int64 indices."""
+    _dev_check(sorted_vals, F64, 'sorted_vals')
+    _dev_check(values, F64, 'values')
+    if side not in ('left', 'right'):
+        raise ValueError("side must be 'left' or 'right'")
+    out = torch.empty(values.numel(), dtype=I64, device=values.device)
+    with torch.cuda.device(values.device):
+        _lib.call('godot_search_sorted', _p(sorted_vals), sorted_vals.numel(), _p(values), values.numel(),
+                  int(side == 'right'), _p(out), _stream(values.device))
+    return out
+
+
+def piecewise_lookup(stops, scales, t):
+    """scales[searchsorted(stops, t)] for event times t."""
+    for x, nm in ((stops, 'stops'), (scales, 'scales'), (t, 't')):
+        _dev_check(x, F64, nm)
+    if stops.numel() != scales.numel() or stops.numel() == 0:
+        raise ValueError('stops and scales must be non-empty and of equal length')
+    out = torch.empty(t.numel(), dtype=F64, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.call('godot_piecewise_lookup', _p(stops), _p(scales), stops.numel(), _p(t), t.numel(), _p(out),
+                  _stream(t.device))
+    return out
+
+
+def rescale_weights(w, a=1.0, b=1.0):
+    """a w / (a w + b (1 - w)); a, b scalars or per-photon tensors."""
+    _dev_check(w, F64, 'w')
+    at, a0 = _per_cell(a, w.numel(), w.device, 'a')
+    bt, b0 = _per_cell(b, w.numel(), w.device, 'b')
+    out = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _lib.call('godot_rescale_weights', _p(w), _p(at), a0, _p(bt), b0, w.numel(), _p(out), _stream(w.device))
+    return out
+
+
 def bin_photons(ti, start0, stops):
     _dev_check(ti, F64, 'ti')
     _dev_check(stops, F64, 'stops')

@@ -182,6 +182,42 @@ int godot_exposure_at(const double *tstart, const double *tstop,
                       double *out_dead, void *workspace, size_t workspace_bytes,
                       godot_stream_t stream);
 
+/* The same two calls when the source- and background-scaled exposures of the
+ * table rows have been rescaled by the caller (Data.apply_scalers,
+ * core.py:2282-2306: sexposure *= src_scaler(TSTART, TSTOP) etc.): the per-row
+ * arrays replace the (S/E), (B/E) multiples of `exposure`.                     */
+int godot_exposure_table_rows(const double *tstart, const double *tstop,
+                              const double *exposure, const double *sexposure,
+                              const double *bexposure, const double *livetime,
+                              int64_t n_ft2, void *table, size_t table_bytes,
+                              godot_stream_t stream);
+int godot_exposure_at_rows(const double *tstart, const double *tstop,
+                           const double *exposure, const double *sexposure,
+                           const double *bexposure, const double *livetime,
+                           int64_t n_ft2, const void *table,
+                           const double *times, int64_t n_t, int cumulative,
+                           double *out_exp, double *out_sexp, double *out_bexp,
+                           double *out_dead, void *workspace, size_t workspace_bytes,
+                           godot_stream_t stream);
+
+/* numpy.searchsorted(sorted, values, side='left' | 'right') on the device: the
+ * photon index ranges of Data.get_cells_from_time_intervals (core.py:2217-2218)
+ * and the insertion points of the randomised variants (core.py:2148-2150, 2240). */
+int godot_search_sorted(const double *sorted, int64_t n, const double *values,
+                        int64_t nv, int right, int64_t *out, godot_stream_t stream);
+
+/* out[k] = scales[searchsorted(stops, t[k])]: PiecewiseScaler called with event
+ * times (scalers.py:46-51; stops/scales are the scaler's padded arrays).        */
+int godot_piecewise_lookup(const double *stops, const double *scales, int64_t nseg,
+                           const double *t, int64_t n, double *out,
+                           godot_stream_t stream);
+
+/* out = a w / (a w + b (1 - w)) (apply_scalers, core.py:2304); a, b per photon
+ * (device arrays) or NULL for the scalars a0, b0.                              */
+int godot_rescale_weights(const double *w, const double *a, double a0,
+                          const double *b, double b0, int64_t n, double *out,
+                          godot_stream_t stream);
+
 /* Photon range of every cell for time-sorted photons: the integer result of
  * searchsorted(ti,[starts[0],stops[-1]]) + searchsorted(stops,times) +
  * bincount (core.py:2097-2099, 2159-2161): photon i belongs to cell c iff

@@ -95,3 +95,12 @@ def test_host_side_value_types():
         ts.get_topo_bins()
     assert abs(float(core.met2mjd(239557417.0)) - 54682.65603) < 1e-4
     assert core.infer_met(3e8) == 3e8
+
+
+def test_piecewise_scaler_host_logic_matches_reference(golden):
+    """The interval arithmetic of PiecewiseScaler runs on the host (no GPU needed)."""
+    from godot_amd.scalers import PiecewiseScaler
+    g = golden('cell_variants.npz')
+    src = PiecewiseScaler(g['s_starts'], g['s_stops'], g['s_scales'])
+    assert np.array_equal(src(g['in_TSTART'], g['in_TSTOP']), g['scaler_rows'])
+    assert np.array_equal(src(g['in_ti']), g['scaler_events'])

@@ -1,0 +1,105 @@
+"""get_cells variants (flux scalers, randomised deal, cells from time
+intervals / contiguous exposures) against the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _data(g):
+    from godot_amd import core
+    return core.Data(g['in_ti'], g['in_we'], g['in_TSTART'], g['in_TSTOP'], g['in_LIVETIME'], g['in_exposure'],
+                     device=DEV)
+
+
+def _scalers(g):
+    from godot_amd.scalers import PiecewiseScaler
+    return (PiecewiseScaler(g['s_starts'], g['s_stops'], g['s_scales']),
+            PiecewiseScaler(g['b_starts'], g['b_stops'], g['b_scales']))
+
+
+def _describe(batch):
+    """Same order-independent per-cell description as the golden generator."""
+    lo, hi = batch.lo.cpu().numpy(), batch.hi.cpu().numpy()
+    we, ti = batch.we.cpu().numpy(), batch.ti.cpu().numpy()
+    st = batch.starts.cpu().numpy()
+    return dict(starts=st, stops=batch.stops.cpu().numpy(), exp=batch.sexp.cpu().numpy(),
+                SonB=(batch.sexp / batch.bexp).cpu().numpy(), counts=hi - lo,
+                wsum=np.array([np.sum(np.sort(we[a:b])) for a, b in zip(lo, hi)]),
+                w2sum=np.array([np.sum(np.sort(we[a:b]) ** 2) for a, b in zip(lo, hi)]),
+                tsum=np.array([np.sum(np.sort(ti[a:b] - s)) for a, b, s in zip(lo, hi, st)]))
+
+
+def _same(d, g, prefix, exact=('starts', 'stops', 'counts'), rtol=1e-12):
+    for k, v in d.items():
+        ref = g[prefix + k]
+        if k in exact:
+            assert np.array_equal(v, ref), (prefix, k)
+        else:
+            assert np.allclose(v, ref, rtol=rtol, atol=0), (prefix, k, np.abs(v - ref).max())
+
+
+def test_scaler_values_match_reference(golden):
+    g = golden('cell_variants.npz')
+    src, _ = _scalers(g)
+    assert np.array_equal(src(g['in_TSTART'], g['in_TSTOP']), g['scaler_rows'])
+    assert np.array_equal(src(g['in_ti']), g['scaler_events'])
+    on_dev = src(torch.from_numpy(g['in_ti']).to(DEV)).cpu().numpy()
+    assert np.array_equal(on_dev, g['scaler_events'])
+
+
+def test_scaled_cells_match_reference(golden):
+    g = golden('cell_variants.npz')
+    data = _data(g)
+    src, bkg = _scalers(g)
+    we_before = data.we
+    cells = data.get_cells(tcell=3600., use_barycenter=False, src_scaler=src, bkg_scaler=bkg, quiet=True)
+    assert data.we is we_before and data.sexposure is None      # reverted, as in the reference
+    d = _describe(cells)
+    _same(d, g, 'scaled_', exact=('starts', 'stops', 'counts', 'exp'))
+    lo, hi = cells.lo.cpu().numpy(), cells.hi.cpu().numpy()
+    we = np.concatenate([cells.we.cpu().numpy()[a:b] for a, b in zip(lo, hi)])
+    assert np.array_equal(we, g['scaled_we'])
+    ts = data.get_cells(tcell=3600., use_barycenter=False, src_scaler=src, time_series_only=True, quiet=True)
+    assert np.array_equal(ts.sexp.cpu().numpy(), g['scaled_ts_sexp'])
+    assert np.array_equal(ts.bexp.cpu().numpy(), g['scaled_ts_bexp'])
+    assert np.array_equal(ts.counts.cpu().numpy(), g['scaled_ts_counts'])
+    assert np.allclose(ts.weights.cpu().numpy(), g['scaled_ts_weights'], rtol=1e-12, atol=1e-13)
+    assert np.allclose(ts.weights2.cpu().numpy(), g['scaled_ts_weights2'], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize('prefix,seed,scaled', [('rand_', 3, False), ('randscaled_', 4, True)])
+def test_randomised_deal_matches_reference(golden, prefix, seed, scaled):
+    """Same random stream (numpy default_rng on the host), same insertion points:
+    every cell receives the reference's photons (order inside a cell aside)."""
+    g = golden('cell_variants.npz')
+    data = _data(g)
+    kw = dict(src_scaler=_scalers(g)[0]) if scaled else {}
+    cells = data.get_cells(tcell=3600., use_barycenter=False, randomize=True, seed=seed, quiet=True, **kw)
+    _same(_describe(cells), g, prefix, exact=('starts', 'stops', 'counts', 'exp'))
+
+
+def test_contiguous_exposure_cells_match_reference(golden):
+    g = golden('cell_variants.npz')
+    data = _data(g)
+    gs, ge = data.get_contiguous_exposures()
+    assert np.array_equal(gs, g['contig_starts']) and np.array_equal(ge, g['contig_stops'])
+    t0 = g['in_TSTART'][0]
+    gs2, ge2 = data.get_contiguous_exposures(tstart=t0 + 1.2345 * 86400, tstop=t0 + 9.8765 * 86400)
+    assert np.array_equal(gs2, g['contig2_starts']) and np.array_equal(ge2, g['contig2_stops'])
+    cells = data.get_contiguous_exposure_cells()
+    _same(_describe(cells), g, 'contig_', exact=('starts', 'stops', 'counts', 'exp'))
+    cells = data.get_contiguous_exposure_cells(randomize=True, seed=5)
+    _same(_describe(cells), g, 'contigrand_', exact=('starts', 'stops', 'counts', 'exp'), rtol=1e-9)
+
+
+def test_search_sorted_matches_numpy():
+    from godot_amd import ops
+    rng = np.random.default_rng(2)
+    a = np.sort(rng.integers(0, 50, 1000).astype(float))
+    v = np.concatenate([rng.uniform(-5, 55, 500), a[::7], [-1e9, 1e9]])
+    for side in ('left', 'right'):
+        out = ops.search_sorted(torch.from_numpy(a).to(DEV), torch.from_numpy(v).to(DEV), side=side)
+        assert np.array_equal(out.cpu().numpy(), np.searchsorted(a, v, side=side))
