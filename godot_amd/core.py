@@ -21,7 +21,7 @@ __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries'
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
            'met2mjd', 'mjd2met', 'infer_met', 'power_spectrum_fft', 'power_spectrum_simple',
            'power_spectrum_dft', 'fit_harmonics', 'compute_ls', 'get_orbital_modulation', 'z2m',
-           'h_test', 'PhaseCellsLogLikelihood', 'FitnessRows']
+           'h_test', 'PhaseCellsLogLikelihood', 'FitnessRows', 'PhaseData']
 
 MJDREF = 51910 + 7.428703703703703e-4
 F64 = torch.float64
@@ -112,10 +112,11 @@ class CellBatch(object):
     """Device-resident list of cells; behaves like the list of Cell objects
     the reference's Data.get_cells returns (len, indexing, iteration)."""
 
-    def __init__(self, we, ti, lo, hi, starts, stops, sexp, bexp):
+    def __init__(self, we, ti, lo, hi, starts, stops, sexp, bexp, phase=False):
         self.we, self.ti, self.lo, self.hi = we, ti, lo, hi
         self.starts, self.stops, self.sexp, self.bexp = starts, stops, sexp, bexp
         self.device = we.device
+        self.phase = bool(phase)      # cells of a folded light curve: indexing yields PhaseCell
         self._host = None
 
     @classmethod
@@ -155,7 +156,7 @@ class CellBatch(object):
         if isinstance(i, slice):
             return CellBatch(self.we, self.ti, self.lo[i].contiguous(), self.hi[i].contiguous(),
                              self.starts[i].contiguous(), self.stops[i].contiguous(),
-                             self.sexp[i].contiguous(), self.bexp[i].contiguous())
+                             self.sexp[i].contiguous(), self.bexp[i].contiguous(), phase=self.phase)
         h = self._hostcopy()
         n = len(h['lo'])
         if i < 0:
@@ -163,8 +164,9 @@ class CellBatch(object):
         if not 0 <= i < n:
             raise IndexError('cell index out of range')
         l, u = int(h['lo'][i]), int(h['hi'][i])
-        return Cell(h['starts'][i], h['stops'][i], h['sexp'][i], _np(self.ti[l:u]),
-                    _np(self.we[l:u]), h['sexp'][i] / h['bexp'][i])
+        return (PhaseCell if self.phase else Cell)(h['starts'][i], h['stops'][i], h['sexp'][i],
+                                                   _np(self.ti[l:u]), _np(self.we[l:u]),
+                                                   h['sexp'][i] / h['bexp'][i])
 
     def __iter__(self):
         for i in range(len(self)):
@@ -203,7 +205,7 @@ class CellBatch(object):
             sexp[b] = np.asarray(h['sexp'][s:e]).sum()
             bexp[b] = np.asarray(h['bexp'][s:e]).sum()
         return CellBatch(we, ti, lo, hi, _to_dev(starts, dev), _to_dev(stops, dev), _to_dev(sexp, dev),
-                         _to_dev(bexp, dev))
+                         _to_dev(bexp, dev), phase=self.phase)
 
 
 def _as_batch(cells, device=None):
@@ -669,7 +671,7 @@ class PhaseCellsLogLikelihood(CellsLogLikelihood):
         self.cells = CellBatch(b.we, b.ti, rep(b.lo), rep(b.hi),
                                torch.cat([b.starts - 1, b.starts, b.starts + 1]).contiguous(),
                                torch.cat([b.stops - 1, b.stops, b.stops + 1]).contiguous(),
-                               rep(b.sexp), rep(b.bexp))
+                               rep(b.sexp), rep(b.bexp), phase=True)
         self._cr = self.cells.ranges()
         self.profile_background = False
 
@@ -955,6 +957,46 @@ class Data(object):
             return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
                                   timesys='topocentric', minimum_exposure=0)
         return CellBatch(we, ti, lo, hi, starts, stops, sexp, bexp)
+
+
+class PhaseData(object):
+    """Pulse phases instead of times, exposure ignored (reference core.py:2319-2386).
+    Constructed from arrays of phases in [0, 1) and weights (the reference reads
+    them from FT1 files)."""
+
+    def __init__(self, phases, weights, phase_shift=None, device=None):
+        dev = device or default_device()
+        ph = np.asarray(_np(phases), dtype=np.float64).copy()
+        we = np.asarray(_np(weights), dtype=np.float64)
+        if phase_shift is not None:
+            ph += phase_shift
+            np.mod(ph, 1, out=ph)
+        a = np.argsort(ph)
+        self.device = dev
+        self.ti = _to_dev(ph[a], dev)
+        self.we = _to_dev(we[a], dev)
+        self.E = 1
+        self.S = float(np.sum(we[a]))
+        self.B = len(we) - self.S
+
+    def get_cells(self, ncell=100, get_converse=False, randomize=False, seed=None):
+        dev = self.device
+        edges = np.linspace(0, 1, ncell + 1)
+        starts, stops = _to_dev(edges[:-1], dev), _to_dev(edges[1:], dev)
+        times, weights = self.ti, self.we
+        if get_converse:
+            weights = 1 - weights
+        if randomize:
+            # new uniform phases from numpy's default_rng (host), sorted; no ties among them
+            times, order = torch.sort(_to_dev(np.random.default_rng(seed).random(times.numel()), dev))
+            weights = weights[order].contiguous()
+        idx = ops.search_sorted(stops, times)
+        counts = torch.bincount(idx, minlength=ncell)[:ncell]
+        off = torch.cat([torch.zeros(1, dtype=I64, device=dev), torch.cumsum(counts, 0)])
+        sexp = torch.full((ncell,), self.S / ncell, dtype=F64, device=dev)
+        bexp = sexp / (self.S / self.B)
+        return CellBatch(weights.contiguous(), times.contiguous(), off[:-1].contiguous(), off[1:].contiguous(),
+                         starts, stops, sexp, bexp, phase=True)
 
 
 # ---------------------------------------------------------------------------

@@ -103,3 +103,32 @@ def test_search_sorted_matches_numpy():
     for side in ('left', 'right'):
         out = ops.search_sorted(torch.from_numpy(a).to(DEV), torch.from_numpy(v).to(DEV), side=side)
         assert np.array_equal(out.cpu().numpy(), np.searchsorted(a, v, side=side))
+
+
+def test_phase_cells_and_folded_bayesian_blocks_match_reference(golden):
+    """PhaseData.get_cells (plain, converse, randomised) and Bayesian Blocks on the
+    folded light curve wrapped three times (PhaseCellsLogLikelihood)."""
+    from godot_amd import core
+    g = golden('phase_cells.npz')
+    pd = core.PhaseData(g['phases'], g['weights'], device=DEV)
+    cells = pd.get_cells(ncell=50)
+    _same(_describe(cells), g, 'plain_', exact=('starts', 'stops', 'counts', 'exp'))
+    _same(_describe(pd.get_cells(ncell=20, get_converse=True)), g, 'converse_',
+          exact=('starts', 'stops', 'counts', 'exp'))
+    _same(_describe(pd.get_cells(ncell=50, randomize=True, seed=9)), g, 'rand_',
+          exact=('starts', 'stops', 'counts', 'exp'))
+    assert isinstance(cells[3], core.PhaseCell)
+    pcl = core.PhaseCellsLogLikelihood(cells)
+    rows, idx = pcl.get_bb_lightcurve(tsmin=4, bb_prior=8, get_indices=True)
+    assert np.array_equal(idx, g['bb_idx'])
+    ref = g['bb_rows']
+    assert np.array_equal(rows[:, 4] == -1, ref[:, 4] == -1)
+    tol = 1e-9 * np.maximum(np.abs(ref), 1.0)
+    tol[:, 5] *= np.maximum(1.0, np.abs(ref[:, 5]))
+    assert (np.abs(rows - ref) <= tol).all(), np.abs(rows - ref).max(0)
+    raw = core.CellsLogLikelihood(cells).get_raw_lightcurve()
+    rr = g['raw_rows']
+    assert np.array_equal(raw[:, 4] == -1, rr[:, 4] == -1)
+    tol = 1e-9 * np.maximum(np.abs(rr), 1.0)
+    tol[:, 5] *= np.maximum(1.0, np.abs(rr[:, 5]))
+    assert (np.abs(raw - rr) <= tol).all()
