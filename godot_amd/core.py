@@ -21,7 +21,7 @@ __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries'
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
            'met2mjd', 'mjd2met', 'infer_met', 'power_spectrum_fft', 'power_spectrum_simple',
            'power_spectrum_dft', 'fit_harmonics', 'compute_ls', 'get_orbital_modulation', 'z2m',
-           'h_test', 'PhaseCellsLogLikelihood', 'FitnessRows', 'PhaseData']
+           'h_test', 'PhaseCellsLogLikelihood', 'FitnessRows', 'PhaseData', 'bb_prior_tune']
 
 MJDREF = 51910 + 7.428703703703703e-4
 F64 = torch.float64
@@ -997,6 +997,25 @@ class PhaseData(object):
         bexp = sexp / (self.S / self.B)
         return CellBatch(weights.contiguous(), times.contiguous(), off[:-1].contiguous(), off[1:].contiguous(),
                          starts, stops, sexp, bexp, phase=True)
+
+
+def bb_prior_tune(data, tcell, bb_priors=[2, 3, 4, 5, 6, 7, 8, 9, 10], ntrial=10, orbital=False,
+                  **cell_kwargs):
+    """Number of Bayesian blocks found in randomised realisations of the data for a
+    range of prior parameters (reference core.py:2784-2817).  Returns
+    (counts [len(bb_priors), ntrial], number of cells)."""
+    rvals = np.empty((len(bb_priors), ntrial), dtype=int)
+    for itrial in range(ntrial):
+        if orbital:
+            cells = data.get_contiguous_exposure_cells(randomize=True, **cell_kwargs)
+        elif isinstance(data, PhaseData):
+            cells = data.get_cells(tcell, randomize=True, **cell_kwargs)
+        else:
+            cells = data.get_cells(tcell=tcell, randomize=True, **cell_kwargs)
+        cll = CellsLogLikelihood(cells)
+        for iprior, prior in enumerate(bb_priors):
+            rvals[iprior, itrial] = len(cll.do_bb(prior=prior)[0])
+    return rvals, len(cells)
 
 
 # ---------------------------------------------------------------------------

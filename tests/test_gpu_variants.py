@@ -132,3 +132,14 @@ def test_phase_cells_and_folded_bayesian_blocks_match_reference(golden):
     tol = 1e-9 * np.maximum(np.abs(rr), 1.0)
     tol[:, 5] *= np.maximum(1.0, np.abs(rr[:, 5]))
     assert (np.abs(raw - rr) <= tol).all()
+
+
+def test_bb_prior_tune_matches_reference(golden):
+    from godot_amd import core
+    g = golden('bb_prior_tune.npz')
+    data = _data(g)
+    priors = [int(x) for x in g['priors']]
+    r1, n1 = core.bb_prior_tune(data, 7200., bb_priors=priors, ntrial=2, use_barycenter=False, seed=7, quiet=True)
+    assert n1 == int(g['tune_ncell']) and np.array_equal(r1, g['tune_cells'])
+    r2, n2 = core.bb_prior_tune(data, None, bb_priors=priors, ntrial=1, orbital=True, seed=8)
+    assert n2 == int(g['tune_orbital_ncell']) and np.array_equal(r2, g['tune_orbital'])
