@@ -7,8 +7,12 @@
 // wave-uniform (scalar) loads, so there is no cross-lane reduction and no LDS
 // traffic in the inner loop.  Per photon the thread forms the exact phase of
 // its first frequency once (double-double product, polynomial sin/cos) and
-// then steps through its J frequencies by rotating the phasor with the
-// photon's precomputed exp(2 pi i t df).
+// then steps through its J frequencies with the three-term recurrence
+// z[k+1] = 2 cos(d) z[k] - z[k-1], d = 2 pi t df: one fused multiply-add per
+// component and step.  A rounding error made at step j reaches step k scaled
+// by sin((k-j) d) / sin(d), at most k - j, so the error after J steps is below
+// J^2 / 2 ulp whatever d is.  The harmonics of one frequency come from the
+// same recurrence in the harmonic index.
 #include "common.hpp"
 
 namespace {
@@ -49,9 +53,10 @@ struct PhotonRow {
     double uh;   // frac(t df): high part, cycles in [-0.5, 0.5]
     double ul;   //             low part
     double w;    // weight
+    double tcd;  // 2 cos(2 pi t df)
     double cd;   // cos(2 pi t df)
     double sd;   // sin(2 pi t df)
-    double pad0, pad1;
+    double sqw;  // sqrt(w), NaN for a negative weight
 };
 
 __global__ void z2m_prepare_kernel(const double *t, const double *w, int64_t nph, double f0, double df,
@@ -82,33 +87,55 @@ __global__ void z2m_prepare_kernel(const double *t, const double *w, int64_t nph
     r.uh = uh;
     r.ul = ul;
     r.w = w[i];
+    r.tcd = cd2 + cd2;
     r.cd = cd2;
     r.sd = sd2;
-    r.pad0 = r.pad1 = 0.0;
+    r.sqw = sqrt(r.w);
     rows[i] = r;
 }
 
-// deterministic sum of w^2 by one workgroup
+// deterministic sum of w^2 by one workgroup; out[1] = 1 when some weight is
+// negative or NaN (the sqrt(w) phasor of the M = 2 kernel needs w >= 0)
 __global__ __launch_bounds__(1024) void sumsq_kernel(const double *w, int64_t n, double *out)
 {
     __shared__ double part[1024 / WAVE];
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s = fma(w[i], w[i], s);
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        s = fma(w[i], w[i], s);
+        bad |= !(w[i] >= 0.0);
+    }
     s = team_sum<WAVE>(s);
+    bad = __syncthreads_or(bad);
     if ((threadIdx.x % WAVE) == 0) part[threadIdx.x / WAVE] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int k = 0; k < 1024 / WAVE; ++k) tot += part[k];
-        *out = tot;
+        out[0] = tot;
+        out[1] = bad ? 1.0 : 0.0;
     }
 }
 
 constexpr int Z_THREADS = 256;
 
+// Frequencies per thread for m = 1 and m = 2 (measured best on MI355X: the
+// sin/cos of the first frequency costs about 50 instructions per photon and
+// thread, a further frequency 4 or 7) and the waves per SIMD that leaves.
+#ifndef Z_J12
+#define Z_J12 20
+#define Z_W2 2
+#endif
+#ifndef Z_J1
+#define Z_J1 24
+#endif
+// Waves per SIMD the kernels are compiled for (their launch bounds); with 256
+// CUs of 4 SIMDs this fixes how many workgroups are resident at a time.
+constexpr int z2m_waves(int m) { return m == 2 ? Z_W2 : ((m == 1 || m == 5 || m >= 9) ? 4 : 3); }
+
 // Accumulate the 2M trig sums of J frequencies over photons [i0, i1).
 // acc layout: [k][h][0 = cos, 1 = sin].
-template <int M, int J>
+template <int M, int J, bool SQ>
 __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ rows, int64_t i0, int64_t i1,
                                                double jb, double (&acc)[J][M][2])
 {
@@ -121,34 +148,59 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
         x -= rint(x);
         double s, c;
         sincos_cycles(x, s, c);
+        if constexpr (SQ) {
+            // Non-negative weights, M == 2.  The phasor carries the amplitude sqrt(w), so that its square is
+            // w exp(2 i phi): harmonic 2 is three multiply-adds on (c, s), with
+            // the sine sum left at half its value until the loop is over.
+            c *= r.sqw;
+            s *= r.sqw;
+            double cp = fma(c, r.cd, s * r.sd), sp = fma(s, r.cd, -(c * r.sd));
+#pragma unroll
+            for (int k = 0; k < J; ++k) {
+                acc[k][0][0] = fma(r.sqw, c, acc[k][0][0]);
+                acc[k][0][1] = fma(r.sqw, s, acc[k][0][1]);
+                acc[k][1][0] = fma(c, c, acc[k][1][0]);
+                acc[k][1][0] = fma(-s, s, acc[k][1][0]);
+                acc[k][1][1] = fma(c, s, acc[k][1][1]);
+                if (k + 1 < J) {
+                    double cn = fma(r.tcd, c, -cp), sn = fma(r.tcd, s, -sp);
+                    cp = c;
+                    sp = s;
+                    c = cn;
+                    s = sn;
+                }
+            }
+            continue;
+        }
+        double cp = fma(c, r.cd, s * r.sd), sp = fma(s, r.cd, -(c * r.sd));
 #pragma unroll
         for (int k = 0; k < J; ++k) {
-            if (M == 2) {
-                // harmonic 2 from the double-angle forms, 2w folded into the weight
-                acc[k][0][0] = fma(r.w, c, acc[k][0][0]);
-                acc[k][0][1] = fma(r.w, s, acc[k][0][1]);
-                double w2 = r.w + r.w;
-                acc[k][1][0] = fma(w2, fma(c, c, -0.5), acc[k][1][0]);
-                acc[k][1][1] = fma(w2, c * s, acc[k][1][1]);
-            } else {
-                double ch = c, sh = s;
+            const double t2 = c + c;
+            double chm = 1.0, shm = 0.0, ch = c, sh = s;
 #pragma unroll
-                for (int h = 0; h < M; ++h) {
-                    acc[k][h][0] = fma(r.w, ch, acc[k][h][0]);
-                    acc[k][h][1] = fma(r.w, sh, acc[k][h][1]);
-                    if (h + 1 < M) {
-                        double cn = fma(ch, c, -(sh * s));
-                        sh = fma(sh, c, ch * s);
-                        ch = cn;
-                    }
+            for (int h = 0; h < M; ++h) {
+                acc[k][h][0] = fma(r.w, ch, acc[k][h][0]);
+                acc[k][h][1] = fma(r.w, sh, acc[k][h][1]);
+                if (h + 1 < M) {
+                    double cn = fma(t2, ch, -chm), sn = fma(t2, sh, -shm);
+                    chm = ch;
+                    shm = sh;
+                    ch = cn;
+                    sh = sn;
                 }
             }
             if (k + 1 < J) {
-                double cn = fma(c, r.cd, -(s * r.sd));
-                s = fma(s, r.cd, c * r.sd);
+                double cn = fma(r.tcd, c, -cp), sn = fma(r.tcd, s, -sp);
+                cp = c;
+                sp = s;
                 c = cn;
+                s = sn;
             }
         }
+    }
+    if constexpr (SQ) {
+#pragma unroll
+        for (int k = 0; k < J; ++k) acc[k][1][1] += acc[k][1][1];
     }
 }
 
@@ -173,31 +225,37 @@ __device__ __forceinline__ void z2m_finish(const double (&acc)[J][M][2], double 
 }
 
 // One launch over all photons: thread -> J frequencies, finish in-kernel.
-template <int M, int J>
-__global__ __launch_bounds__(Z_THREADS) void z2m_kernel(const PhotonRow *__restrict__ rows, int64_t nph,
-                                                        const double *sumw2, int64_t j0, int64_t nf,
-                                                        double *z2, double *h)
+// For M = 2 both variants are launched and the weight-sign flag sumw2[1]
+// decides which of them runs.
+template <int M, int J, bool SQ>
+__global__ __launch_bounds__(Z_THREADS, z2m_waves(M)) void z2m_kernel(const PhotonRow *__restrict__ rows,
+                                                                      int64_t nph, const double *sumw2,
+                                                                      int64_t j0, int64_t nf, double *z2,
+                                                                      double *h)
 {
     const int64_t jrel = ((int64_t)blockIdx.x * Z_THREADS + threadIdx.x) * J;
     if (jrel >= nf) return;
+    if (M == 2 && (sumw2[1] == 0.0) != SQ) return;
     double acc[J][M][2];
 #pragma unroll
     for (int k = 0; k < J; ++k)
 #pragma unroll
         for (int hh = 0; hh < M; ++hh) acc[k][hh][0] = acc[k][hh][1] = 0.0;
-    z2m_accumulate<M, J>(rows, 0, nph, (double)(j0 + jrel), acc);
+    z2m_accumulate<M, J, SQ>(rows, 0, nph, (double)(j0 + jrel), acc);
     z2m_finish<M, J>(acc, 2.0 / *sumw2, jrel, nf, z2, h);
 }
 
 // Few frequencies: photons are split over gridDim.y chunks, partial sums go to
 // `part` [chunk][freq][M][2] and a second launch adds them in chunk order.
-template <int M, int J>
-__global__ __launch_bounds__(Z_THREADS) void z2m_partial_kernel(const PhotonRow *__restrict__ rows,
-                                                                int64_t nph, int64_t j0, int64_t nf,
-                                                                double *part)
+template <int M, int J, bool SQ>
+__global__ __launch_bounds__(Z_THREADS, z2m_waves(M)) void z2m_partial_kernel(const PhotonRow *__restrict__ rows,
+                                                                              int64_t nph, const double *sumw2,
+                                                                              int64_t j0, int64_t nf,
+                                                                              double *part)
 {
     const int64_t jrel = ((int64_t)blockIdx.x * Z_THREADS + threadIdx.x) * J;
     if (jrel >= nf) return;
+    if (M == 2 && (sumw2[1] == 0.0) != SQ) return;
     const int64_t per = (nph + gridDim.y - 1) / gridDim.y;
     const int64_t i0 = (int64_t)blockIdx.y * per;
     const int64_t i1 = i0 + per < nph ? i0 + per : nph;
@@ -206,7 +264,7 @@ __global__ __launch_bounds__(Z_THREADS) void z2m_partial_kernel(const PhotonRow 
     for (int k = 0; k < J; ++k)
 #pragma unroll
         for (int hh = 0; hh < M; ++hh) acc[k][hh][0] = acc[k][hh][1] = 0.0;
-    z2m_accumulate<M, J>(rows, i0, i1, (double)(j0 + jrel), acc);
+    z2m_accumulate<M, J, SQ>(rows, i0, i1, (double)(j0 + jrel), acc);
     double *o = part + ((int64_t)blockIdx.y * nf + jrel) * (M * 2);
 #pragma unroll
     for (int k = 0; k < J; ++k) {
@@ -245,20 +303,31 @@ __global__ void z2m_combine_kernel(const double *part, int nchunk, int m, const 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // frequencies per thread for m harmonics (register budget: 2 m J doubles)
-inline int z2m_J(int m) { return m <= 2 ? 16 : (m <= 4 ? 8 : (m <= 8 ? 4 : (m <= 10 ? 2 : 1))); }
+inline int z2m_J(int m) { return m == 1 ? Z_J1 : m == 2 ? Z_J12 : (m <= 4 ? 8 : (m <= 8 ? 4 : (m <= 10 ? 2 : 1))); }
 
-constexpr int Z_MIN_BLOCKS = 1024;   // below this many workgroups, split the photons too
+constexpr int Z_SIMDS = 256 * 4;
 constexpr int Z_MAX_CHUNKS = 64;
 
+// Number of photon chunks (gridDim.y).  A launch runs in rounds of `resident`
+// workgroups; a last round that is only partly full runs as long as a full one,
+// so the chunk count is chosen to make blocks * chunks fill whole rounds.
 inline int z2m_chunks(int64_t nph, int64_t nf, int m)
 {
-    int64_t blocks = ceil_div(nf, (int64_t)Z_THREADS * z2m_J(m));
-    if (blocks >= Z_MIN_BLOCKS) return 1;
-    int64_t c = ceil_div(Z_MIN_BLOCKS, blocks);
+    const int64_t blocks = ceil_div(nf, (int64_t)Z_THREADS * z2m_J(m));
+    const int64_t resident = (int64_t)Z_SIMDS * z2m_waves(m) / (Z_THREADS / WAVE);
     int64_t cmax = nph / 2048 > 1 ? nph / 2048 : 1;
-    if (c > cmax) c = cmax;
-    if (c > Z_MAX_CHUNKS) c = Z_MAX_CHUNKS;
-    return (int)c;
+    if (cmax > Z_MAX_CHUNKS) cmax = Z_MAX_CHUNKS;
+    int best = 1;
+    double best_cost = (double)ceil_div(blocks, resident);
+    for (int64_t c = 2; c <= cmax; ++c) {
+        double cost = (double)ceil_div(blocks * c, resident) / (double)c;
+        if (cost < 0.97 * best_cost) {
+            best = (int)c;
+            best_cost = cost;
+        }
+        if (blocks * c >= 8 * resident) break;
+    }
+    return best;
 }
 
 template <int M, int J>
@@ -267,11 +336,17 @@ int z2m_launch(const PhotonRow *rows, int64_t nph, const double *sumw2, int64_t 
 {
     unsigned gx = (unsigned)ceil_div(nf, (int64_t)Z_THREADS * J);
     if (chunks <= 1) {
-        hipLaunchKernelGGL((z2m_kernel<M, J>), dim3(gx), dim3(Z_THREADS), 0, st, rows, nph, sumw2, j0, nf, z2,
-                           h);
+        hipLaunchKernelGGL((z2m_kernel<M, J, false>), dim3(gx), dim3(Z_THREADS), 0, st, rows, nph, sumw2, j0,
+                           nf, z2, h);
+        if constexpr (M == 2)
+            hipLaunchKernelGGL((z2m_kernel<M, J, true>), dim3(gx), dim3(Z_THREADS), 0, st, rows, nph, sumw2,
+                               j0, nf, z2, h);
     } else {
-        hipLaunchKernelGGL((z2m_partial_kernel<M, J>), dim3(gx, (unsigned)chunks), dim3(Z_THREADS), 0, st,
-                           rows, nph, j0, nf, part);
+        hipLaunchKernelGGL((z2m_partial_kernel<M, J, false>), dim3(gx, (unsigned)chunks), dim3(Z_THREADS), 0,
+                           st, rows, nph, sumw2, j0, nf, part);
+        if constexpr (M == 2)
+            hipLaunchKernelGGL((z2m_partial_kernel<M, J, true>), dim3(gx, (unsigned)chunks), dim3(Z_THREADS),
+                               0, st, rows, nph, sumw2, j0, nf, part);
         hipLaunchKernelGGL(z2m_combine_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, st,
                            (const double *)part, chunks, M, sumw2, nf, z2, h);
     }
@@ -519,7 +594,7 @@ extern "C" int godot_z2m(const double *t, const double *w, int64_t nph, double f
 #define Z2M_CASE(M_, J_) \
     case M_: z2m_launch<M_, J_>(rows, nph, sumw2, j0, nf, chunks, part, z2, h, st); break;
     switch (m) {
-        Z2M_CASE(1, 16) Z2M_CASE(2, 16) Z2M_CASE(3, 8) Z2M_CASE(4, 8) Z2M_CASE(5, 4) Z2M_CASE(6, 4)
+        Z2M_CASE(1, Z_J1) Z2M_CASE(2, Z_J12) Z2M_CASE(3, 8) Z2M_CASE(4, 8) Z2M_CASE(5, 4) Z2M_CASE(6, 4)
         Z2M_CASE(7, 4) Z2M_CASE(8, 4) Z2M_CASE(9, 2) Z2M_CASE(10, 2) Z2M_CASE(11, 1) Z2M_CASE(12, 1)
         Z2M_CASE(13, 1) Z2M_CASE(14, 1) Z2M_CASE(15, 1) Z2M_CASE(16, 1) Z2M_CASE(17, 1) Z2M_CASE(18, 1)
         Z2M_CASE(19, 1) Z2M_CASE(20, 1)

@@ -151,6 +151,27 @@ def test_z2m_matches_oracle(m):
     assert np.abs(_n(h) - href).max() <= 1e-12 * max(1.0, np.abs(href).max())
 
 
+@pytest.mark.parametrize('nf', [300, 20 * 256 * 3 + 7, 20 * 256 * 512])
+def test_z2m_negative_weight_takes_general_kernel(nf):
+    """m = 2 carries sqrt(w) in the phasor; a table with a negative weight must
+    give the same sums through the general kernel (single launch and photon split)."""
+    from godot_amd import ops
+    rng = np.random.default_rng(21)
+    nph = 4100
+    t = np.sort(rng.uniform(0, 3.2e8, nph))
+    w = rng.uniform(0.0, 1.0, nph)
+    f0, df = 1.5e-3, 7.3e-10
+    zpos, _ = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=2)
+    ref = orc.z2m(t, w, f0, df, min(nf, 400), m=2)
+    assert np.abs(_n(zpos)[:len(ref)] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    w[17] = -0.25
+    w[3000] = -0.5
+    zneg, hneg = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=2, want_h=True)
+    ref = orc.z2m(t, w, f0, df, min(nf, 400), m=2)
+    assert np.abs(_n(zneg)[:len(ref)] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert np.isfinite(_n(zneg)).all() and np.isfinite(_n(hneg)).all()
+
+
 def test_z2m_signal_and_exactness_at_large_phase():
     """A pulsed signal is recovered at its frequency after 1e10 cycles; the
     single-launch and photon-split paths agree."""
@@ -174,6 +195,6 @@ def test_z2m_signal_and_exactness_at_large_phase():
                     f0, df, 51, m=2)
     assert abs(_n(z3)[50] - ze) <= 1e-9 * max(1, ze)
     # many frequencies -> one launch over all photons; must equal the split path
-    nf = 256 * 16 * 1100
+    nf = 256 * 20 * 1024     # whole residency rounds: not split
     zbig, _ = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=2)
     assert np.abs(_n(zbig[:101]) - z).max() <= 1e-9 * z.max()
