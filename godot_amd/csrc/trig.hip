@@ -300,6 +300,16 @@ __global__ void z2m_combine_kernel(const double *part, int nchunk, int m, const 
     if (h) h[j] = hbest;
 }
 
+// part [chunk][freq][m][2] -> sums [freq][m][2], chunks added in order
+__global__ void z2m_add_chunks_kernel(const double *part, int nchunk, int64_t n, double *sums)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double t = 0.0;
+    for (int q = 0; q < nchunk; ++q) t += part[(int64_t)q * n + i];
+    sums[i] = t;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // frequencies per thread for m harmonics (register budget: 2 m J doubles)
@@ -349,6 +359,26 @@ int z2m_launch(const PhotonRow *rows, int64_t nph, const double *sumw2, int64_t 
                                0, st, rows, nph, sumw2, j0, nf, part);
         hipLaunchKernelGGL(z2m_combine_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, st,
                            (const double *)part, chunks, M, sumw2, nf, z2, h);
+    }
+    return 0;
+}
+
+// Trig sums only: partial kernel for every chunk count; one chunk writes `sums` directly.
+template <int M, int J>
+int z2m_sums_launch(const PhotonRow *rows, int64_t nph, const double *sumw2, int64_t j0, int64_t nf, int chunks,
+                    double *part, double *sums, hipStream_t st)
+{
+    unsigned gx = (unsigned)ceil_div(nf, (int64_t)Z_THREADS * J);
+    double *dst = chunks <= 1 ? sums : part;
+    hipLaunchKernelGGL((z2m_partial_kernel<M, J, false>), dim3(gx, (unsigned)(chunks < 1 ? 1 : chunks)),
+                       dim3(Z_THREADS), 0, st, rows, nph, sumw2, j0, nf, dst);
+    if constexpr (M == 2)
+        hipLaunchKernelGGL((z2m_partial_kernel<M, J, true>), dim3(gx, (unsigned)(chunks < 1 ? 1 : chunks)),
+                           dim3(Z_THREADS), 0, st, rows, nph, sumw2, j0, nf, dst);
+    if (chunks > 1) {
+        int64_t n = nf * M * 2;
+        hipLaunchKernelGGL(z2m_add_chunks_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                           (const double *)part, chunks, n, sums);
     }
     return 0;
 }
@@ -601,6 +631,62 @@ extern "C" int godot_z2m(const double *t, const double *w, int64_t nph, double f
     }
 #undef Z2M_CASE
     GODOT_LAUNCH_CHECK("godot_z2m");
+    return GODOT_OK;
+}
+
+extern "C" int godot_z2m_sums(const double *t, const double *w, int64_t nph, double f0, double df, int64_t j0,
+                              int64_t nf, int m, double *sums, double *sumw2_out, void *workspace,
+                              size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_REQUIRE(nph >= 0 && nf >= 0 && j0 >= 0, GODOT_E_INVALID, "godot_z2m_sums: negative size");
+    GODOT_REQUIRE(m >= 1 && m <= 20, GODOT_E_UNSUPPORTED, "godot_z2m_sums: m must be in [1, 20]");
+    GODOT_REQUIRE(j0 + nf < ((int64_t)1 << 52), GODOT_E_UNSUPPORTED,
+                  "godot_z2m_sums: frequency index too large");
+    GODOT_REQUIRE(sumw2_out, GODOT_E_INVALID, "godot_z2m_sums: null sumw2 output");
+    GODOT_REQUIRE(sums || nf == 0, GODOT_E_INVALID, "godot_z2m_sums: null sums output");
+    GODOT_REQUIRE((t && w) || nph == 0, GODOT_E_INVALID, "godot_z2m_sums: null photon pointer");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_z2m_workspace_bytes(nph, nf, m), GODOT_E_WORKSPACE,
+                  "godot_z2m_sums: workspace smaller than godot_z2m_workspace_bytes(nph, nf, m)");
+    hipStream_t st = (hipStream_t)stream;
+    PhotonRow *rows = (PhotonRow *)workspace;
+    size_t off = align256(sizeof(PhotonRow) * (size_t)nph);
+    double *sumw2 = (double *)((char *)workspace + off);
+    double *part = (double *)((char *)workspace + off + 256);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, w, nph, sumw2);
+    GODOT_REQUIRE(hipMemcpyAsync(sumw2_out, sumw2, sizeof(double), hipMemcpyDeviceToDevice, st) == hipSuccess,
+                  GODOT_E_LAUNCH, "godot_z2m_sums: copy of sum(w^2) failed");
+    if (nf == 0) {
+        GODOT_LAUNCH_CHECK("godot_z2m_sums");
+        return GODOT_OK;
+    }
+    if (nph > 0)
+        hipLaunchKernelGGL(z2m_prepare_kernel, dim3((unsigned)ceil_div(nph, 256)), dim3(256), 0, st, t, w, nph,
+                           f0, df, rows);
+    int chunks = z2m_chunks(nph, nf, m);
+#define Z2M_CASE(M_, J_) \
+    case M_: z2m_sums_launch<M_, J_>(rows, nph, sumw2, j0, nf, chunks, part, sums, st); break;
+    switch (m) {
+        Z2M_CASE(1, Z_J1) Z2M_CASE(2, Z_J12) Z2M_CASE(3, 8) Z2M_CASE(4, 8) Z2M_CASE(5, 4) Z2M_CASE(6, 4)
+        Z2M_CASE(7, 4) Z2M_CASE(8, 4) Z2M_CASE(9, 2) Z2M_CASE(10, 2) Z2M_CASE(11, 1) Z2M_CASE(12, 1)
+        Z2M_CASE(13, 1) Z2M_CASE(14, 1) Z2M_CASE(15, 1) Z2M_CASE(16, 1) Z2M_CASE(17, 1) Z2M_CASE(18, 1)
+        Z2M_CASE(19, 1) Z2M_CASE(20, 1)
+    }
+#undef Z2M_CASE
+    GODOT_LAUNCH_CHECK("godot_z2m_sums");
+    return GODOT_OK;
+}
+
+extern "C" int godot_z2m_finish(const double *sums, const double *sumw2, int64_t nf, int m, double *z2,
+                                double *h, godot_stream_t stream)
+{
+    GODOT_REQUIRE(nf >= 0, GODOT_E_INVALID, "godot_z2m_finish: negative size");
+    GODOT_REQUIRE(m >= 1 && m <= 20, GODOT_E_UNSUPPORTED, "godot_z2m_finish: m must be in [1, 20]");
+    if (nf == 0) return GODOT_OK;
+    GODOT_REQUIRE(sums && sumw2, GODOT_E_INVALID, "godot_z2m_finish: null input");
+    GODOT_REQUIRE(z2 || h, GODOT_E_INVALID, "godot_z2m_finish: both outputs are null");
+    hipLaunchKernelGGL(z2m_combine_kernel, dim3((unsigned)ceil_div(nf, 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums, 1, m, sumw2, nf, z2, h);
+    GODOT_LAUNCH_CHECK("godot_z2m_finish");
     return GODOT_OK;
 }
 

@@ -9,10 +9,16 @@ The path shards without any data-path exchange:
   * multi-source batches: sources dealt round-robin;
   * Bayesian-Blocks fitness rows: contiguous row ranges balanced by row length
     (row i costs i + 1 cell profiles); the profiles are replicated.
-The only collectives are result collection: an all-gather of fixed-width
-per-cell records (padded to the largest shard) and, for searches, an
-all-reduce(max) / all-gather of per-rank maxima.  Both are latency-bound
+The only collectives there are result collection: an all-gather of
+fixed-width per-cell records (padded to the largest shard) and, for searches,
+an all-reduce(max) / all-gather of per-rank maxima.  Both are latency-bound
 (KBs to a few MB), one hop on the xGMI mesh.
+
+One variant has a real exchange step: a Z^2_m search whose photon list is
+split over the ranks (a list too long to replicate, or already spread by the
+loader).  Every rank forms the trig sums of its photons for a tile of
+frequencies, the tiles are added with all-reduce(sum) (2 m doubles per
+frequency), and every rank finishes the statistic from the totals.
 """
 import numpy as np
 import torch
@@ -126,6 +132,45 @@ def search_sharded(nf, search_fn, gather_spectrum=False, group=None):
         sizes = [frequency_shard(nf, r, world)[1] for r in range(world)]
         spec = all_gather_ragged(z, sizes=sizes, group=group)
     return float(best[0].cpu()), int(best[1].cpu()), spec
+
+
+def photon_shard(nph, rank=None, world=None, group=None):
+    """(first_photon, last_photon_exclusive) of this rank's contiguous share of nph photons."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return (nph * rank) // world, (nph * (rank + 1)) // world
+
+
+def search_photon_sharded(nf, sums_fn, finish_fn, tile=1 << 20, group=None):
+    """Z^2_m / H over nf trial frequencies with the photons split over the ranks.
+
+    sums_fn   : callable(j0, n) -> (sums (n, m, 2) tensor, sumw2 (1,) tensor) for
+                THIS rank's photons (ops.z2m_sums with the rank's photon slice)
+    finish_fn : callable(total_sums, total_sumw2) -> (n,) statistic tensor
+                (ops.z2m_finish)
+    Frequencies are processed in tiles of `tile`: one all-reduce(sum) of
+    2 m tile doubles each (32 MB at m = 2, tile = 2**20), so the exchange of one
+    tile can overlap the kernel of the next on another stream.  Returns the full
+    spectrum on every rank.
+    """
+    rank, world = _world(group)
+    out = []
+    w2_total = None
+    for j0 in range(0, nf, tile):
+        n = min(tile, nf - j0)
+        sums, sumw2 = sums_fn(j0, n)
+        if world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            if w2_total is None:
+                w2_total = sumw2.clone()
+                dist.all_reduce(w2_total, op=dist.ReduceOp.SUM, group=group)
+        else:
+            w2_total = sumw2
+        out.append(finish_fn(sums, w2_total))
+    if not out:
+        return torch.empty(0, dtype=torch.float64)
+    return torch.cat(out)
 
 
 def bb_row_shard(ncell, rank=None, world=None, group=None):

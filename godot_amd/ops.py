@@ -427,6 +427,37 @@ def z2m(t, w, f0, df, nf, m=2, j0=0, want_z2=True, want_h=False, workspace=None)
     return z, h
 
 
+def z2m_sums(t, w, f0, df, nf, m=2, j0=0, workspace=None):
+    """Trig sums of one photon list: (nf, m, 2) tensor of (cos, sin) sums and the
+    device scalar sum(w^2).  Sums of disjoint photon lists add."""
+    _dev_check(t, F64, 't')
+    _dev_check(w, F64, 'w')
+    if t.numel() != w.numel():
+        raise ValueError('t and w must have equal lengths')
+    dev = t.device
+    need = _lib.lib.godot_z2m_workspace_bytes(t.numel(), nf, m)
+    ws = workspace if workspace is not None else _workspace(need, dev)
+    sums = torch.empty((nf, m, 2), dtype=F64, device=dev)
+    sumw2 = torch.empty(1, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_z2m_sums', _p(t), _p(w), t.numel(), float(f0), float(df), int(j0), int(nf), int(m),
+                  _p(sums), _p(sumw2), _p(ws), ws.numel(), _stream(dev))
+    return sums, sumw2
+
+
+def z2m_finish(sums, sumw2, want_z2=True, want_h=False):
+    """Z^2_m and/or H from total trig sums (nf, m, 2) and the total sum(w^2)."""
+    _dev_check(sums, F64, 'sums')
+    _dev_check(sumw2, F64, 'sumw2')
+    nf, m = sums.shape[0], sums.shape[1]
+    dev = sums.device
+    z = torch.empty(nf, dtype=F64, device=dev) if want_z2 else None
+    h = torch.empty(nf, dtype=F64, device=dev) if want_h else None
+    with torch.cuda.device(dev):
+        _lib.call('godot_z2m_finish', _p(sums), _p(sumw2), int(nf), int(m), _p(z), _p(h), _stream(dev))
+    return z, h
+
+
 def ls_cells(flux, tmid, freqs):
     for t, nm in ((flux, 'flux'), (tmid, 'tmid'), (freqs, 'freqs')):
         _dev_check(t, F64, nm)

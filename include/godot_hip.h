@@ -340,6 +340,20 @@ int godot_z2m(const double *t, const double *w, int64_t nph,
               double *z2, double *h, void *workspace, size_t workspace_bytes,
               godot_stream_t stream);
 
+/* The two halves of godot_z2m, for a photon list that is split over devices:
+ * every device forms the trig sums of its own photons, the caller adds them
+ * (and the sum(w^2) scalars) across devices, and godot_z2m_finish turns the
+ * totals into the statistics.  No counterpart in the reference.
+ *   sums       output [nf][m][2]: sum_i w_i cos(2 pi k f_j t_i), then the sine
+ *   sumw2_out  output [1] (device): sum_i w_i^2 of this photon list
+ * Workspace as for godot_z2m.                                                 */
+int godot_z2m_sums(const double *t, const double *w, int64_t nph,
+                   double f0, double df, int64_t j0, int64_t nf, int m,
+                   double *sums, double *sumw2_out,
+                   void *workspace, size_t workspace_bytes, godot_stream_t stream);
+int godot_z2m_finish(const double *sums, const double *sumw2, int64_t nf, int m,
+                     double *z2, double *h, godot_stream_t stream);
+
 /* ---- Bayesian Blocks on the cached profiles ---------------------------------
  * CellsLogLikelihood.fitness (core.py:1108-1136) for every row at once: with
  * dom, cod the [ncell][npt] profiles of godot_cell_logpdf, row i (cells 0..i)

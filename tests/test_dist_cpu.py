@@ -63,6 +63,19 @@ def _worker(rank, world, port, q):
         full = orc.z2m(t, w, 1e-3, 2e-7, nf, m=2)
         ok2 = (jmax == int(np.argmax(full))) and (zmax == full.max()) and \
             np.array_equal(spec.numpy(), full)
+        # the same search with the photons split over the ranks: sums are all-reduced
+        p0, p1 = gd.photon_shard(len(t))
+
+        def sums_fn(j0, n):
+            C, Sn = orc.z2m_trig_sums(t[p0:p1], w[p0:p1], 1e-3, 2e-7, j0 + np.arange(n), 2)
+            return (torch.from_numpy(np.stack([C.T, Sn.T], axis=2).copy()),
+                    torch.tensor([np.sum(w[p0:p1] ** 2)]))
+
+        def finish_fn(sums, sumw2):
+            return (2. / sumw2) * (sums ** 2).sum(dim=(1, 2))
+
+        zps = gd.search_photon_sharded(nf, sums_fn, finish_fn, tile=40).numpy()
+        ok2 = ok2 and len(zps) == nf and np.abs(zps - full).max() <= 1e-12 * full.max()
         # Bayesian-Blocks fitness rows, sharded by row
         nb, npt = 23, 16
         lo = rng.uniform(0, 2, nb)

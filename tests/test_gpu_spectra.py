@@ -172,6 +172,33 @@ def test_z2m_negative_weight_takes_general_kernel(nf):
     assert np.isfinite(_n(zneg)).all() and np.isfinite(_n(hneg)).all()
 
 
+@pytest.mark.parametrize('m', [1, 2, 5])
+def test_z2m_sums_of_photon_shards_add(m):
+    """Trig sums of two photon shards add up to the whole list's statistic, and
+    the sums themselves match the oracle's."""
+    from godot_amd import ops
+    rng = np.random.default_rng(30 + m)
+    nph = 6001
+    t = np.sort(rng.uniform(0, 3.2e8, nph))
+    w = np.clip(rng.beta(0.3, 1.5, nph), 1e-6, 1 - 1e-6)
+    f0, df, nf, j0 = 2.5e-3, 6.1e-10, 333, 4567
+    td, wd = torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV)
+    cut = 2500
+    s1, q1 = ops.z2m_sums(td[:cut].contiguous(), wd[:cut].contiguous(), f0, df, nf, m=m, j0=j0)
+    s2, q2 = ops.z2m_sums(td[cut:].contiguous(), wd[cut:].contiguous(), f0, df, nf, m=m, j0=j0)
+    C, Sn = orc.z2m_trig_sums(t[:cut], w[:cut], f0, df, j0 + np.arange(nf), m)
+    scale = np.sqrt(np.sum(w[:cut] ** 2))
+    assert np.abs(_n(s1)[:, :, 0] - C.T).max() <= 1e-12 * scale
+    assert np.abs(_n(s1)[:, :, 1] - Sn.T).max() <= 1e-12 * scale
+    assert abs(float(q1) - np.sum(w[:cut] ** 2)) <= 1e-12 * np.sum(w ** 2)
+    z, h = ops.z2m_finish(s1 + s2, q1 + q2, want_h=True)
+    zw, hw = ops.z2m(td, wd, f0, df, nf, m=m, j0=j0, want_h=True)
+    assert np.abs(_n(z) - _n(zw)).max() <= 1e-12 * max(1.0, _n(zw).max())
+    assert np.abs(_n(h) - _n(hw)).max() <= 1e-12 * max(1.0, np.abs(_n(hw)).max())
+    ref = orc.z2m(t, w, f0, df, nf, m=m, j0=j0)
+    assert np.abs(_n(z) - ref).max() <= 1e-12 * max(1.0, ref.max())
+
+
 def test_z2m_signal_and_exactness_at_large_phase():
     """A pulsed signal is recovered at its frequency after 1e10 cycles; the
     single-launch and photon-split paths agree."""
