@@ -59,15 +59,22 @@ def event_time_ms(fn, iters, stream):
     return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
 
-def cpu_baseline(s, tcell, seconds):
-    """The oracle's per-cell get_max + get_ts on one core, bounded in time."""
-    from oracle import godot_oracle as orc
-    # bin a leading slice of the same photon list (binning itself is not timed)
+def _cpu_sample(s, tcell):
+    """Arrays of a leading slice (40 days) of the workload, small enough to hand to worker processes."""
     t_end = s['TSTART'][0] + 40 * 86400.
     m = s['ti'] < t_end
     r = s['TSTOP'] <= t_end
-    b = orc.bin_cells(s['ti'][m], s['we'][m], s['TSTART'][r], s['TSTOP'][r], s['exposure'][r],
-                      s['LIVETIME'][r], s['S'], s['B'], s['E'], tcell=tcell)
+    return dict(ti=s['ti'][m], we=s['we'][m], TSTART=s['TSTART'][r], TSTOP=s['TSTOP'][r],
+                exposure=s['exposure'][r], LIVETIME=s['LIVETIME'][r], S=s['S'], B=s['B'], E=s['E'],
+                tcell=tcell)
+
+
+def _cpu_worker(p, seconds):
+    """The oracle's per-cell get_max + get_ts over the sample, repeated for `seconds`: (cells, time, ncell)."""
+    from oracle import godot_oracle as orc
+    # binning itself is not timed
+    b = orc.bin_cells(p['ti'], p['we'], p['TSTART'], p['TSTOP'], p['exposure'], p['LIVETIME'], p['S'], p['B'],
+                      p['E'], tcell=p['tcell'])
     clls = orc.cells_from_bins(b)
     n = 0
     t0 = time.perf_counter()
@@ -79,10 +86,30 @@ def cpu_baseline(s, tcell, seconds):
                 n += 1
             if time.perf_counter() - t0 > seconds:
                 break
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit='cells/s', cores=1, kind='port',
-                sample='oracle get_max+get_ts over the first %d cells (40 days) of the same '
-                       'workload, repeated for %.0f s on one core' % (len(clls), dt))
+    return n, time.perf_counter() - t0, len(clls)
+
+
+def cpu_baseline(s, tcell, seconds):
+    """The oracle on the host cores: one core (the reference is single-threaded), then the
+    same loop in one process per core.  Must run before this process touches the GPU: the
+    workers are spawned."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    p = _cpu_sample(s, tcell)
+    n, dt, ncl = _cpu_worker(p, seconds)
+    out = dict(value=n / dt, unit='cells/s', cores=1, kind='port',
+               sample='oracle get_max+get_ts over the first %d cells (40 days) of the same '
+                      'workload, repeated for %.0f s on one core' % (ncl, dt))
+    cores = max(1, min(16, os.cpu_count() or 1))
+    try:
+        with ProcessPoolExecutor(cores, mp_context=mp.get_context('spawn')) as ex:
+            res = list(ex.map(_cpu_worker, [p] * cores, [seconds / 2] * cores))
+        out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), unit='cells/s',
+                                cores=cores,
+                                sample='the same loop in %d processes, %.0f s each' % (cores, seconds / 2))
+    except Exception as e:   # a box that cannot spawn workers still reports the one-core figure
+        out['all_cores'] = dict(value=None, error=repr(e))
+    return out
 
 
 def main():
@@ -96,14 +123,18 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    stream = torch.cuda.current_stream(dev)
-
     from godot_amd import core, ops, synth
 
     # ---- workload: C2, one photon list per rank ---------------------------------
     s = synth.synth(args.nph, years=args.years, seed=11 + rank)
+    # CPU comparator first, while this process has not initialised the GPU (it spawns workers)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(s, args.tcell, args.cpu_seconds)
+
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    stream = torch.cuda.current_stream(dev)
     data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'],
                      device=dev)
     torch.cuda.synchronize()
@@ -256,10 +287,6 @@ def main():
                                         interpolations_per_s=1000.0 * nb * (nb + 1) / 2 / tb[0])
         del bcll
         torch.cuda.empty_cache()
-
-    cpu = None
-    if world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(s, args.tcell, args.cpu_seconds)
 
     line = {
         'metric': 'cells fit/s + photon×freq evals/s (1/2/4/8 GPU), % HBM/FP64 roofline',
