@@ -119,19 +119,17 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const double *w, int64_t n,
 
 constexpr int Z_THREADS = 256;
 
-// Frequencies per thread for m = 1 and m = 2 (measured best on MI355X: the
-// sin/cos of the first frequency costs about 50 instructions per photon and
-// thread, a further frequency 4 or 7) and the waves per SIMD that leaves.
-#ifndef Z_J12
-#define Z_J12 20
-#define Z_W2 2
+// Frequencies per thread.  The sin/cos of a thread's first frequency costs
+// about 50 instructions per photon, a further frequency 4 (m = 1), 7 (m = 2)
+// or 4m + 1, so J is as large as the registers allow: about 96 running sums
+// (192 VGPRs) at two waves per SIMD; m = 1 keeps four waves (measured best).
+#ifndef Z_JCAP
+#define Z_JCAP 48
 #endif
-#ifndef Z_J1
-#define Z_J1 24
-#endif
+constexpr int z2m_J(int m) { return m == 1 ? 24 : m == 2 ? 20 : Z_JCAP / m; }
 // Waves per SIMD the kernels are compiled for (their launch bounds); with 256
 // CUs of 4 SIMDs this fixes how many workgroups are resident at a time.
-constexpr int z2m_waves(int m) { return m == 2 ? Z_W2 : ((m == 1 || m == 5 || m >= 9) ? 4 : 3); }
+constexpr int z2m_waves(int m) { return m == 1 ? 4 : 2; }
 
 // Accumulate the 2M trig sums of J frequencies over photons [i0, i1).
 // acc layout: [k][h][0 = cos, 1 = sin].
@@ -312,8 +310,6 @@ __global__ void z2m_add_chunks_kernel(const double *part, int nchunk, int64_t n,
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// frequencies per thread for m harmonics (register budget: 2 m J doubles)
-inline int z2m_J(int m) { return m == 1 ? Z_J1 : m == 2 ? Z_J12 : (m <= 4 ? 8 : (m <= 8 ? 4 : (m <= 10 ? 2 : 1))); }
 
 constexpr int Z_SIMDS = 256 * 4;
 constexpr int Z_MAX_CHUNKS = 64;
@@ -621,13 +617,12 @@ extern "C" int godot_z2m(const double *t, const double *w, int64_t nph, double f
                            f0, df, rows);
     hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, st, w, nph, sumw2);
     int chunks = z2m_chunks(nph, nf, m);
-#define Z2M_CASE(M_, J_) \
-    case M_: z2m_launch<M_, J_>(rows, nph, sumw2, j0, nf, chunks, part, z2, h, st); break;
+#define Z2M_CASE(M_) \
+    case M_: z2m_launch<M_, z2m_J(M_)>(rows, nph, sumw2, j0, nf, chunks, part, z2, h, st); break;
     switch (m) {
-        Z2M_CASE(1, Z_J1) Z2M_CASE(2, Z_J12) Z2M_CASE(3, 8) Z2M_CASE(4, 8) Z2M_CASE(5, 4) Z2M_CASE(6, 4)
-        Z2M_CASE(7, 4) Z2M_CASE(8, 4) Z2M_CASE(9, 2) Z2M_CASE(10, 2) Z2M_CASE(11, 1) Z2M_CASE(12, 1)
-        Z2M_CASE(13, 1) Z2M_CASE(14, 1) Z2M_CASE(15, 1) Z2M_CASE(16, 1) Z2M_CASE(17, 1) Z2M_CASE(18, 1)
-        Z2M_CASE(19, 1) Z2M_CASE(20, 1)
+        Z2M_CASE(1) Z2M_CASE(2) Z2M_CASE(3) Z2M_CASE(4) Z2M_CASE(5) Z2M_CASE(6) Z2M_CASE(7)
+        Z2M_CASE(8) Z2M_CASE(9) Z2M_CASE(10) Z2M_CASE(11) Z2M_CASE(12) Z2M_CASE(13) Z2M_CASE(14)
+        Z2M_CASE(15) Z2M_CASE(16) Z2M_CASE(17) Z2M_CASE(18) Z2M_CASE(19) Z2M_CASE(20)
     }
 #undef Z2M_CASE
     GODOT_LAUNCH_CHECK("godot_z2m");
@@ -663,13 +658,12 @@ extern "C" int godot_z2m_sums(const double *t, const double *w, int64_t nph, dou
         hipLaunchKernelGGL(z2m_prepare_kernel, dim3((unsigned)ceil_div(nph, 256)), dim3(256), 0, st, t, w, nph,
                            f0, df, rows);
     int chunks = z2m_chunks(nph, nf, m);
-#define Z2M_CASE(M_, J_) \
-    case M_: z2m_sums_launch<M_, J_>(rows, nph, sumw2, j0, nf, chunks, part, sums, st); break;
+#define Z2M_CASE(M_) \
+    case M_: z2m_sums_launch<M_, z2m_J(M_)>(rows, nph, sumw2, j0, nf, chunks, part, sums, st); break;
     switch (m) {
-        Z2M_CASE(1, Z_J1) Z2M_CASE(2, Z_J12) Z2M_CASE(3, 8) Z2M_CASE(4, 8) Z2M_CASE(5, 4) Z2M_CASE(6, 4)
-        Z2M_CASE(7, 4) Z2M_CASE(8, 4) Z2M_CASE(9, 2) Z2M_CASE(10, 2) Z2M_CASE(11, 1) Z2M_CASE(12, 1)
-        Z2M_CASE(13, 1) Z2M_CASE(14, 1) Z2M_CASE(15, 1) Z2M_CASE(16, 1) Z2M_CASE(17, 1) Z2M_CASE(18, 1)
-        Z2M_CASE(19, 1) Z2M_CASE(20, 1)
+        Z2M_CASE(1) Z2M_CASE(2) Z2M_CASE(3) Z2M_CASE(4) Z2M_CASE(5) Z2M_CASE(6) Z2M_CASE(7)
+        Z2M_CASE(8) Z2M_CASE(9) Z2M_CASE(10) Z2M_CASE(11) Z2M_CASE(12) Z2M_CASE(13) Z2M_CASE(14)
+        Z2M_CASE(15) Z2M_CASE(16) Z2M_CASE(17) Z2M_CASE(18) Z2M_CASE(19) Z2M_CASE(20)
     }
 #undef Z2M_CASE
     GODOT_LAUNCH_CHECK("godot_z2m_sums");

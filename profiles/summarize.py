@@ -29,12 +29,12 @@ def kernel_stats(root):
         print()
 
 
-def counters(root, sub, title):
+def counters(root, sub, title, match='cell_fit', add=False):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in find(os.path.join(root, sub), '*counter_collection.csv'):
         for row in csv.DictReader(open(f)):
             k = row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
-            if 'cell_fit' not in k:
+            if match not in k:
                 continue
             acc[k.split('(')[0]][row['Counter_Name']].append(float(row['Counter_Value']))
     out = {}
@@ -43,7 +43,7 @@ def counters(root, sub, title):
     for k, d in acc.items():
         for c, v in sorted(d.items()):
             print('%-60s %-28s launches=%-4d mean=%.6g' % (k[:60], c, len(v), sum(v) / len(v)))
-            out[c] = sum(v) / len(v)
+            out[c] = (out.get(c, 0.0) if add else 0.0) + sum(v) / len(v)
     if acc:
         print()
     return out
@@ -55,6 +55,21 @@ def main():
     f = counters(root, 'pmc_fetch', 'rocprofv3 --pmc FETCH_SIZE (KB)')
     w = counters(root, 'pmc_write', 'rocprofv3 --pmc WRITE_SIZE (KB)')
     counters(root, 'pmc_sq', 'rocprofv3 --pmc SQ_* instruction mix')
+    z = counters(root, 'pmc_z2m', 'rocprofv3 --pmc SQ_INSTS_VALU_*_F64: python3 profiles/z2m_once.py',
+                 match='z2m_kernel', add=True)
+    if z:
+        zj = os.path.join(root, 'z2m_once.json')
+        evals = json.load(open(zj))['evals'] if os.path.exists(zj) else None
+        fma, add, mul = (z.get('SQ_INSTS_VALU_FMA_F64', 0), z.get('SQ_INSTS_VALU_ADD_F64', 0),
+                         z.get('SQ_INSTS_VALU_MUL_F64', 0))
+        print('# Z^2_m kernel, hardware-counted per launch (wave instructions x 64 lanes):')
+        print(json.dumps({'fp64_fma_lane_ops': fma * 64, 'fp64_add_lane_ops': add * 64,
+                          'fp64_mul_lane_ops': mul * 64, 'fp64_flops': (2 * fma + add + mul) * 64,
+                          'valu_lane_instructions': z.get('SQ_INSTS_VALU', 0) * 64,
+                          'photon_freq_evals': evals,
+                          'fp64_flops_per_eval': (2 * fma + add + mul) * 64 / evals if evals else None,
+                          'valu_instructions_per_eval': z.get('SQ_INSTS_VALU', 0) * 64 / evals if evals else None}))
+        print()
     if f and w:
         fetch, write = f['FETCH_SIZE'], w['WRITE_SIZE']
         # gfx950: FETCH_SIZE tallies 128-B read requests at 64 B -> doubled for streaming reads
