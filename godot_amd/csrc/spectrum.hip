@@ -8,6 +8,9 @@
 // Long transforms take radix-256 passes: two radix-16 butterflies per kernel
 // with a transpose through LDS in between, so a 2^24-point transform is three
 // HBM round trips; what is left of log2 N goes in one more pass (radix 2 .. 128).
+// Their first pass reads the real series themselves (difference of two moment
+// arrays, even/odd packing, zero padding all formed while loading), so the
+// padded complex input never exists in memory.
 // Short transforms (N < 4096) take plain radix-16 passes (one thread = one
 // 16-point butterfly in registers).  Reads are coalesced, writes come in runs
 // of >= 256 bytes.  Twiddles are computed in registers from an exactly reduced
@@ -130,6 +133,39 @@ __global__ __launch_bounds__(256) void stockham_pass_kernel(const cplx *__restri
     for (int r = 0; r < R; ++r) dst[j0 + r * Ns] = v[r];
 }
 
+// ---- packing real series into the complex input ---------------------------
+
+// z[n] = x[2n] + i x[2n+1] for a series x of n_in samples zero-padded to 2N.
+// kind selects the series built on the fly from the per-bin moments.
+enum Series { SER_PLAIN = 0, SER_DIFF = 1 };
+
+struct PackArgs {
+    const double *a;   // plain: x = a ; diff: x = a - b
+    const double *b;
+    int64_t n_in;      // samples available
+    int64_t fold;      // 0, or the length at which the series is wrapped (x[n] + x[n + fold])
+};
+
+__device__ __forceinline__ double series_at(const PackArgs &p, int64_t i)
+{
+    if (i >= p.n_in) return 0.0;
+    double v = p.a[i];
+    if (p.b) v -= p.b[i];
+    return v;
+}
+
+__device__ __forceinline__ double series_folded(const PackArgs &p, int64_t i)
+{
+    double v = series_at(p, i);
+    if (p.fold > 0)
+        for (int64_t q = i + p.fold; q < p.n_in; q += p.fold) v += series_at(p, q);
+    return v;
+}
+
+struct PackBatch {
+    PackArgs s[3];
+};
+
 // Two Stockham passes in one kernel: radix R = A * 16 (A = 2 .. 16).  A workgroup
 // takes 16 consecutive butterflies of R points; 16 threads share one of them.
 // With r = t + 16 m and q = q_lo + A q_hi:
@@ -138,8 +174,11 @@ __global__ __launch_bounds__(256) void stockham_pass_kernel(const cplx *__restri
 // through LDS (transposed), thread q_lo forms the outer 16-point transforms.
 // One HBM round trip instead of two.  FIRST: the pass with Ns = 1 (no outer
 // twiddles; results of one butterfly are contiguous, so lanes run over q_lo).
-template <int A, bool FIRST>
-__global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restrict__ in,
+// PACKED (with FIRST): the input is not a complex buffer but the real series
+// themselves, z[n] = x[2n] + i x[2n+1] formed while loading; samples past the
+// end of a zero-padded series cost no memory traffic.
+template <int A, bool FIRST, bool PACKED>
+__global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restrict__ in, PackBatch pb,
                                                              cplx *__restrict__ out, int64_t N, int64_t Ns)
 {
     constexpr int R = A * 16;
@@ -154,8 +193,17 @@ __global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restr
     const cplx *src = in + (int64_t)blockIdx.y * N;
     cplx *dst = out + (int64_t)blockIdx.y * N;
     cplx v[A];
+    if constexpr (PACKED) {
+        const PackArgs &p = pb.s[blockIdx.y];
 #pragma unroll
-    for (int m = 0; m < A; ++m) v[m] = src[j + (int64_t)(t + 16 * m) * S];
+        for (int m = 0; m < A; ++m) {
+            const int64_t n = j + (int64_t)(t + 16 * m) * S;
+            v[m] = cplx{series_folded(p, 2 * n), series_folded(p, 2 * n + 1)};
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < A; ++m) v[m] = src[j + (int64_t)(t + 16 * m) * S];
+    }
     if (!FIRST) {
         // x_r *= exp(-2 pi i k r / (Ns R)), r = t + 16 m: exp(-2 pi i k t / (Ns R)) times
         // powers of exp(-2 pi i 16 k / (Ns R)); both angles are exact binary fractions
@@ -203,14 +251,28 @@ __global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restr
     }
 }
 
+__global__ void pack_kernel(PackBatch pb, int64_t N, cplx *z);
+
 // Complex forward FFT of `batch` series of power-of-two length N >= 2.
-// Returns the buffer (a or b) that holds the result.
-cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
+// Returns the buffer (a or b) that holds the result.  The input is the
+// content of `a`, or, with `pack`, the real series it describes (batch <= 3):
+// long transforms form the complex input inside their first pass, short ones
+// pack it into `a` first.
+cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st, const PackBatch *pack = nullptr)
 {
     int lg = 0;
     while (((int64_t)1 << lg) < N) ++lg;
     int64_t Ns = 1;
     cplx *src = a, *dst = b;
+    const bool packed_first = pack && lg >= 12;
+    if (packed_first) {
+        src = b;   // not read by the first pass; it writes a
+        dst = a;
+    } else if (pack) {
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)batch), dim3(256), 0, st, *pack,
+                           N, a);
+    }
+    const PackBatch nopack{};
     auto launch = [&](int R) {
         dim3 grid((unsigned)ceil_div(N / R, 256), (unsigned)batch);
         switch (R) {
@@ -238,13 +300,18 @@ cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
 #define FUSED(A_)                                                                                     \
     if (A == A_) {                                                                                    \
         if (first)                                                                                    \
-            hipLaunchKernelGGL((stockham_fused_kernel<A_, true>), grid, dim3(256), 0, st,             \
-                               (const cplx *)src, dst, N, Ns);                                        \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, true, false>), grid, dim3(256), 0, st,      \
+                               (const cplx *)src, nopack, dst, N, Ns);                                \
         else                                                                                          \
-            hipLaunchKernelGGL((stockham_fused_kernel<A_, false>), grid, dim3(256), 0, st,            \
-                               (const cplx *)src, dst, N, Ns);                                        \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, false, false>), grid, dim3(256), 0, st,     \
+                               (const cplx *)src, nopack, dst, N, Ns);                                \
     }
-        FUSED(2) FUSED(4) FUSED(8) FUSED(16)
+        if (first && packed_first) {
+            hipLaunchKernelGGL((stockham_fused_kernel<16, true, true>), grid, dim3(256), 0, st,
+                               (const cplx *)nullptr, *pack, dst, N, Ns);
+        } else {
+            FUSED(2) FUSED(4) FUSED(8) FUSED(16)
+        }
 #undef FUSED
         Ns *= R;
         cplx *t = src;
@@ -267,39 +334,6 @@ cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st)
     for (int p = 0; p < lg / 4; ++p) launch(16);
     return src;
 }
-
-// ---- packing real series into the complex input ---------------------------
-
-// z[n] = x[2n] + i x[2n+1] for a series x of n_in samples zero-padded to 2N.
-// kind selects the series built on the fly from the per-bin moments.
-enum Series { SER_PLAIN = 0, SER_DIFF = 1 };
-
-struct PackArgs {
-    const double *a;   // plain: x = a ; diff: x = a - b
-    const double *b;
-    int64_t n_in;      // samples available
-    int64_t fold;      // 0, or the length at which the series is wrapped (x[n] + x[n + fold])
-};
-
-__device__ __forceinline__ double series_at(const PackArgs &p, int64_t i)
-{
-    if (i >= p.n_in) return 0.0;
-    double v = p.a[i];
-    if (p.b) v -= p.b[i];
-    return v;
-}
-
-__device__ __forceinline__ double series_folded(const PackArgs &p, int64_t i)
-{
-    double v = series_at(p, i);
-    if (p.fold > 0)
-        for (int64_t q = i + p.fold; q < p.n_in; q += p.fold) v += series_at(p, q);
-    return v;
-}
-
-struct PackBatch {
-    PackArgs s[3];
-};
 
 __global__ void pack_kernel(PackBatch pb, int64_t N, cplx *z)
 {
@@ -592,8 +626,7 @@ extern "C" int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out
     cplx *b = (cplx *)((char *)workspace + align256(sizeof(cplx) * (size_t)N));
     PackBatch pb{};
     pb.s[0] = PackArgs{x, nullptr, n < l ? n : l, 0};
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N, 256), 1), dim3(256), 0, st, pb, N, a);
-    cplx *Z = fft_c2c(a, b, N, 1, st);
+    cplx *Z = fft_c2c(a, b, N, 1, st, &pb);
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)ceil_div(N + 1, 256)), dim3(256), 0, st, (const cplx *)Z, N,
                        N + 1, (cplx *)out);
     GODOT_LAUNCH_CHECK("godot_rfft_f64");
@@ -647,13 +680,11 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
     pb2.s[0] = PackArgs{WW, nullptr, n, l / 2};
     pb2.s[1] = PackArgs{WbWb, nullptr, n, l / 2};
     pb2.s[2] = PackArgs{W, WW, n, l / 2};
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N2, 256), 3), dim3(256), 0, st, pb2, N2, a2);
-    cplx *Z2 = fft_c2c(a2, b2, N2, 3, st);
+    cplx *Z2 = fft_c2c(a2, b2, N2, 3, st, &pb2);
     PackBatch pb1{};
     pb1.s[0] = PackArgs{W, S, n, 0};
     pb1.s[1] = PackArgs{Wb, B, n, 0};
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N1, 256), 2), dim3(256), 0, st, pb1, N1, a1);
-    cplx *Z1 = fft_c2c(a1, b1, N1, 2, st);
+    cplx *Z1 = fft_c2c(a1, b1, N1, 2, st, &pb1);
     hipLaunchKernelGGL(ps_epilogue_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0, st, (const cplx *)Z1,
                        N1, (const cplx *)Z2, N2, nk, p0, p1, pb, amps);
     GODOT_LAUNCH_CHECK("godot_power_spectrum_fft");
@@ -687,12 +718,10 @@ extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, co
     cplx *a2 = (cplx *)(ws + 2 * sz1), *b2 = (cplx *)(ws + 2 * sz1 + sz2);
     PackBatch pb2{};
     pb2.s[0] = PackArgs{WW, nullptr, n, l / 2};
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N2, 256), 1), dim3(256), 0, st, pb2, N2, a2);
-    cplx *Z2 = fft_c2c(a2, b2, N2, 1, st);
+    cplx *Z2 = fft_c2c(a2, b2, N2, 1, st, &pb2);
     PackBatch pb1{};
     pb1.s[0] = PackArgs{W, S, n, 0};
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(N1, 256), 1), dim3(256), 0, st, pb1, N1, a1);
-    cplx *Z1 = fft_c2c(a1, b1, N1, 1, st);
+    cplx *Z1 = fft_c2c(a1, b1, N1, 1, st, &pb1);
     hipLaunchKernelGGL(ps_simple_epilogue_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0, st,
                        (const cplx *)Z1, N1, (const cplx *)Z2, N2, nk, dlogl, moments);
     GODOT_LAUNCH_CHECK("godot_power_spectrum_simple");
