@@ -855,12 +855,14 @@ class Data(object):
                   time_series_only=False, use_barycenter=True, randomize=False, seed=None,
                   src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
                   minimum_fractional_exposure=0, quiet=False):
-        if use_barycenter:
+        if use_barycenter and not (hasattr(self, '_t2b') and hasattr(self, '_b2t')):
             raise NotImplementedError(
-                'use_barycenter=True needs the astropy ephemeris of the reference\'s bary '
-                'module, which this package does not carry; pass use_barycenter=False')
+                'use_barycenter=True needs the time converters that the reference builds from '
+                'its astropy ephemeris (bary.py); hand them in with '
+                'set_barycenter_converters(topo2bary, bary2topo), or pass use_barycenter=False')
         if tcell is None:
             raise NotImplementedError('photon-based cells (tcell=None) are not built')
+        ft1_is_bary = self.timeref == 'SOLARSYSTEM'
         if tstart is None:
             tstart = self._t0
         tstart = float(infer_met(tstart))
@@ -878,27 +880,67 @@ class Data(object):
                 print('Will clip to MET=%.2f.' % (self._t1))
             tstop = self._t1
 
+        if use_barycenter:
+            tstart, tstop = (float(x) for x in self._topo2bary([tstart, tstop]))
+
         ncell = int((tstop - tstart) / tcell)
         if ncell == 0:
             tcell = tstop - tstart
             ncell = 1
         edges_h = tstart + np.arange(ncell + 1) * tcell
         assert(edges_h[-1] <= tstop)
-        edges = torch.from_numpy(edges_h).to(self.device)
-        self._topo_edges = edges_h.copy()
+        if use_barycenter:
+            # uniform cells at the barycentre: nonuniform edges at the observatory, which
+            # is where exposure (and, for topocentric photon times, the binning) is done
+            topo_h = np.array(self._bary2topo(edges_h), dtype=np.float64)
+            assert(abs(topo_h[0] - self._t0) < 1e-6)
+            topo_h[0] = self._t0   # fix tiny numerical error
+            assert(topo_h[-1] <= self._t1)
+            bary_h = edges_h
+        else:
+            topo_h = bary_h = edges_h
+        self._topo_edges = topo_h.copy()
 
         # apply scales if provided (reverted before returning, as the reference does)
         ov = self.apply_scalers(src_scaler=src_scaler, bkg_scaler=bkg_scaler)
         try:
-            return self._cells_on_edges(edges, edges_h, trim_zero_exposure, time_series_only, randomize,
-                                        seed, src_injector, minimum_fractional_exposure)
+            return self._cells_on_edges(topo_h, bary_h, ft1_is_bary, use_barycenter, trim_zero_exposure,
+                                        time_series_only, randomize, seed, src_injector,
+                                        minimum_fractional_exposure)
         finally:
             self.revert_scalers(ov)
 
-    def _cells_on_edges(self, edges, edges_h, trim_zero_exposure, time_series_only, randomize, seed,
-                        src_injector, minimum_fractional_exposure):
-        exp, sexp, bexp, dead = self.get_exposure(edges, deadtime_too=True, cumulative=False)
+    def set_barycenter_converters(self, topo2bary, bary2topo):
+        """Callables mapping arrays of topocentric METs to barycentric ones and back: what
+        the reference's get_topo2bary_interpolator / get_bary2topo_interpolator return
+        (core.py:1784-1790) and caches under these same attribute names."""
+        self._t2b = topo2bary
+        self._b2t = bary2topo
+
+    def _topo2bary(self, topo_times):
+        return np.asarray(self._t2b(np.asarray(topo_times, dtype=np.float64)), dtype=np.float64)
+
+    def _bary2topo(self, bary_times):
+        return np.asarray(self._b2t(np.asarray(bary_times, dtype=np.float64)), dtype=np.float64)
+
+    def _cells_on_edges(self, topo_h, bary_h, ft1_is_bary, use_barycenter, trim_zero_exposure,
+                        time_series_only, randomize, seed, src_injector, minimum_fractional_exposure):
+        """The array tail of get_cells (reference core.py:2087-2206).  topo_h: cell edges
+        at the observatory (exposure); bary_h: the same edges at the barycentre (equal to
+        topo_h without barycentring).  Photons are binned on the edges of their own time
+        system; the cells are labelled with the barycentric edges when barycentring."""
+        dev = self.device
+        topo = torch.from_numpy(np.ascontiguousarray(topo_h)).to(dev)
+        # always use topocentric times to manage the exposure calculation
+        exp, sexp, bexp, dead = self.get_exposure(topo, deadtime_too=True, cumulative=False)
+        edges_h = bary_h if ft1_is_bary else topo_h
+        edges = topo if edges_h is topo_h else torch.from_numpy(np.ascontiguousarray(edges_h)).to(dev)
         starts, stops = edges[:-1].contiguous(), edges[1:].contiguous()
+        relabel = use_barycenter and not ft1_is_bary
+        if relabel or use_barycenter:
+            bary = torch.from_numpy(np.ascontiguousarray(bary_h)).to(dev)
+            label_starts, label_stops = bary[:-1].contiguous(), bary[1:].contiguous()
+            alt_starts, alt_stops = topo[:-1].contiguous(), topo[1:].contiguous()
 
         if minimum_fractional_exposure > 0:
             frac = exp / exp[exp > 0].mean()
@@ -915,6 +957,9 @@ class Data(object):
             exp, sexp, bexp = ops.gather(exp, keep), ops.gather(sexp, keep), ops.gather(bexp, keep)
             dead = ops.gather(dead, keep)
             lo, hi, counts = ops.gather(lo, keep), ops.gather(hi, keep), ops.gather(counts, keep)
+            if use_barycenter:
+                label_starts, label_stops = ops.gather(label_starts, keep), ops.gather(label_stops, keep)
+                alt_starts, alt_stops = ops.gather(alt_starts, keep), ops.gather(alt_stops, keep)
 
         we, ti = self.we, self.ti
         if src_injector is not None:
@@ -933,7 +978,8 @@ class Data(object):
             times = ops.gather(ti, src)
             sexp_h, bexp_h = _np(sexp), _np(bexp)
             if src_injector is not None:
-                csexp = np.cumsum(src_injector(edges_h[:-1], edges_h[1:]) * sexp_h)
+                # the injector is handed ALL barycentric edges, as in the reference (2135)
+                csexp = np.cumsum(src_injector(bary_h[:-1], bary_h[1:]) * sexp_h)
             else:
                 csexp = np.cumsum(sexp_h)
             csexp *= 1. / csexp[-1]
@@ -952,8 +998,17 @@ class Data(object):
             off = torch.cat([torch.zeros(1, dtype=I64, device=dev), torch.cumsum(counts, 0)])
             lo, hi = off[:-1].contiguous(), off[1:].contiguous()
 
+        # exposure and event selection are done; with barycentring the cells carry the
+        # (uniform) barycentric edges
+        if relabel:
+            starts, stops = label_starts, label_stops
+
         if time_series_only:
             w1, w2 = ops.cell_moments(we, lo, hi)
+            if use_barycenter:
+                return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
+                                      alt_starts=alt_starts, alt_stops=alt_stops,
+                                      timesys='barycenter', minimum_exposure=0)
             return CellTimeSeries(starts, stops, exp, sexp, bexp, counts, w1, w2, dead,
                                   timesys='topocentric', minimum_exposure=0)
         return CellBatch(we, ti, lo, hi, starts, stops, sexp, bexp)

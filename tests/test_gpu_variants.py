@@ -143,3 +143,45 @@ def test_bb_prior_tune_matches_reference(golden):
     assert n1 == int(g['tune_ncell']) and np.array_equal(r1, g['tune_cells'])
     r2, n2 = core.bb_prior_tune(data, None, bb_priors=priors, ntrial=1, orbital=True, seed=8)
     assert n2 == int(g['tune_orbital_ncell']) and np.array_equal(r2, g['tune_orbital'])
+
+
+def _bary_converters(g):
+    """The analytic converters the golden generator handed to the reference."""
+    amp, period, t0 = float(g['bary_amp']), float(g['bary_period']), g['in_TSTART'][0]
+
+    def t2b(t):
+        t = np.asarray(t, dtype=np.float64)
+        return t + amp * np.sin(2 * np.pi * (t - t0) / period)
+
+    def b2t(b):
+        b = np.asarray(b, dtype=np.float64)
+        t = b.copy()
+        for _ in range(6):
+            t = b - amp * np.sin(2 * np.pi * (t - t0) / period)
+        return t
+    return t2b, b2t
+
+
+@pytest.mark.parametrize('timeref,tag', [('LOCAL', 'topo'), ('SOLARSYSTEM', 'ssb')])
+def test_barycentred_cells_match_reference(golden, timeref, tag):
+    """use_barycenter=True with caller-supplied time converters: uniform cells at
+    the barycentre, exposure (and, for topocentric photon times, binning) on the
+    converted edges."""
+    from godot_amd import core
+    g = golden('bary_cells.npz')
+    data = core.Data(g['in_ti'], g['in_we'], g['in_TSTART'], g['in_TSTOP'], g['in_LIVETIME'], g['in_exposure'],
+                     timeref=timeref, device=DEV)
+    with pytest.raises(NotImplementedError):
+        data.get_cells(tcell=3600., use_barycenter=True, quiet=True)
+    data.set_barycenter_converters(*_bary_converters(g))
+    cells = data.get_cells(tcell=3600., use_barycenter=True, quiet=True)
+    assert np.array_equal(data._topo_edges, g[tag + '_topo_edges'])
+    _same(_describe(cells), g, tag + '_', exact=('starts', 'stops', 'counts', 'exp'))
+    ts = data.get_cells(tcell=1800., use_barycenter=True, time_series_only=True, trim_zero_exposure=False,
+                        quiet=True)
+    n = lambda x: x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    for k in ('starts', 'stops', 'exp', 'sexp', 'bexp', 'counts', 'alt_starts', 'alt_stops'):
+        assert np.array_equal(n(getattr(ts, k)), g['%s_ts_%s' % (tag, k)]), k
+    assert np.allclose(n(ts.weights), g[tag + '_ts_weights'], rtol=1e-12, atol=1e-13)
+    assert np.allclose(n(ts.weights2), g[tag + '_ts_weights2'], rtol=1e-12, atol=1e-13)
+    assert ts.timesys == str(g[tag + '_ts_timesys']) == 'barycenter'
