@@ -851,6 +851,72 @@ class Data(object):
         starts, stops = self.get_contiguous_exposures(tstart=tstart, tstop=tstop)
         return self.get_cells_from_time_intervals(starts, stops, randomize=randomize, seed=seed)
 
+    def get_photon_cells(self, tstart, tstop, max_interval=30):
+        """One cell per photon (reference core.py:1862-1956): the cell boundaries lie
+        half way IN EXPOSURE between neighbouring photons, and a gap in the exposure
+        table longer than max_interval seconds ends the cell before it and starts the
+        next one after it.  Exposures, their midpoints and the inversion back to times
+        run on the device; the fix-up at the (few) gaps is done on the host."""
+        dev = self.device
+        tstart, tstop = float(tstart), float(tstop)
+        if tstart < self._t0:
+            raise ValueError('Start time precedes start of exposure!')
+        if tstop > self._t1:
+            raise ValueError('Stop time exceeds stop of exposure!')
+        span = _to_dev(np.array([tstart, tstop]), dev)
+        e0, e1 = (int(x) for x in ops.search_sorted(self.ti, span).cpu())
+        ti = self.ti[e0:e1].contiguous()
+        we = self.we[e0:e1].contiguous()
+        nph = e1 - e0
+        print('have %d photons' % (nph))
+
+        # snap tstart/stop to edges of exposure
+        i0, i1 = (int(x) for x in ops.search_sorted(self.TSTOP, span).cpu())
+        tstart = max(tstart, float(self.TSTART[i0].cpu()))
+        if tstop < float(self.TSTART[i1].cpu()):
+            i1 -= 1
+        tstop = min(tstop, float(self.TSTOP[i1].cpu()))
+
+        # exposure at start, photon times and stop; its midpoints, inverted to times
+        times = torch.cat([_to_dev(np.array([tstart]), dev), ti, _to_dev(np.array([tstop]), dev)])
+        exposure = self.get_exposure(times)[0]
+        mp_exposure = 0.5 * (exposure[1:] + exposure[:-1])
+        n_ft2 = self.TSTART.numel()
+        c = self._exposure_table[:32 * n_ft2].view(F64).view(n_ft2, 4)[:, 0].contiguous()
+        idx = ops.search_sorted(c, mp_exposure)
+        frac = 1 - (c[idx] - mp_exposure) / self.exposure[idx]
+        t0r = self.TSTART[idx]
+        mp_times = t0r + frac * (self.TSTOP[idx] - t0r)
+
+        cell_starts = mp_times[:-1].cpu().numpy().copy()
+        cell_starts[0] = tstart
+        cell_stops = mp_times[1:].cpu().numpy().copy()
+        cell_stops[-1] = tstop
+
+        # gaps in the exposure rows between the snapped start and stop
+        t0s = self.TSTART[i0:i1 + 1].cpu().numpy()
+        t1s = self.TSTOP[i0:i1 + 1].cpu().numpy()
+        is_gap = (t0s[1:] - t1s[:-1]) > max_interval
+        gap_begin, gap_end = t1s[:-1][is_gap], t0s[1:][is_gap]
+        ti_h = ti.cpu().numpy()
+        k = np.searchsorted(cell_stops, gap_end)       # the cell each gap falls into
+        # photon after the gap: the previous cell ends where the gap begins and this one
+        # starts where it ends; photon before the gap: this cell ends at the gap, the
+        # next one starts after it (numpy's assignment order decides repeated cells)
+        after = ((ti_h[k] - gap_end) > 0) | (k == nph - 1)
+        cell_stops[k[after] - 1] = gap_begin[after]
+        cell_starts[k[after]] = gap_end[after]
+        before = ~after
+        cell_stops[k[before]] = gap_begin[before]
+        cell_starts[k[before] + 1] = gap_end[before]
+
+        starts, stops = _to_dev(cell_starts, dev), _to_dev(cell_stops, dev)
+        exp = self.get_exposure(stops)[0] - self.get_exposure(starts)[0]
+        sexp = exp * (self.S / self.E)
+        bexp = sexp / (self.S / self.B)
+        lo = torch.arange(nph, dtype=I64, device=dev)
+        return CellBatch(we, ti, lo, lo + 1, starts, stops, sexp, bexp)
+
     def get_cells(self, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True,
                   time_series_only=False, use_barycenter=True, randomize=False, seed=None,
                   src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
@@ -860,8 +926,6 @@ class Data(object):
                 'use_barycenter=True needs the time converters that the reference builds from '
                 'its astropy ephemeris (bary.py); hand them in with '
                 'set_barycenter_converters(topo2bary, bary2topo), or pass use_barycenter=False')
-        if tcell is None:
-            raise NotImplementedError('photon-based cells (tcell=None) are not built')
         ft1_is_bary = self.timeref == 'SOLARSYSTEM'
         if tstart is None:
             tstart = self._t0
@@ -882,6 +946,9 @@ class Data(object):
 
         if use_barycenter:
             tstart, tstop = (float(x) for x in self._topo2bary([tstart, tstop]))
+
+        if tcell is None:
+            return self.get_photon_cells(tstart, tstop)
 
         ncell = int((tstop - tstart) / tcell)
         if ncell == 0:

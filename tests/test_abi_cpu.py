@@ -104,3 +104,34 @@ def test_piecewise_scaler_host_logic_matches_reference(golden):
     src = PiecewiseScaler(g['s_starts'], g['s_stops'], g['s_scales'])
     assert np.array_equal(src(g['in_TSTART'], g['in_TSTOP']), g['scaler_rows'])
     assert np.array_equal(src(g['in_ti']), g['scaler_events'])
+
+
+def test_cell_timeseries_file_format_is_the_references(tmp_path):
+    """CellTimeSeries.save/load: a file written by the reference loads here, and the
+    file written here has the reference's keys, dtypes and contents."""
+    from godot_amd import core
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cell_timeseries_ref.npz')
+    ts = core.CellTimeSeries.load(ref)
+    assert ts.timesys == 'barycenter' and ts.minimum_exposure == 0.0
+    mine = str(tmp_path / 'mine.npz')
+    ts.save(mine)
+    with np.load(ref, allow_pickle=False) as q, np.load(mine, allow_pickle=False) as m:
+        assert sorted(q.files) == sorted(m.files)
+        for k in q.files:
+            if k == 'metadata':   # [str(minimum_exposure), timesys]; '0' comes back as '0.0', as in the reference
+                assert float(q[k][0]) == float(m[k][0]) and q[k][1] == m[k][1] and m[k].dtype.kind == 'U'
+                continue
+            assert q[k].dtype == m[k].dtype and np.array_equal(q[k], m[k]), k
+        for k in core.CellTimeSeries._KEYS + ['alt_starts', 'alt_stops']:
+            assert np.array_equal(np.asarray(getattr(ts, k)), q[k]), k
+    topo = ts.get_topo_bins()
+    assert np.array_equal(topo[0], ts.alt_starts) and ts.get_bary_bins()[0] is ts.starts
+    # the uncompressed variant and a topocentric series without alternative bins
+    ts2 = core.CellTimeSeries(ts.starts, ts.stops, ts.exp, ts.sexp, ts.bexp, ts.counts, ts.weights, ts.weights2,
+                              ts.deadtime, timesys='topocentric', minimum_exposure=0)
+    f2 = str(tmp_path / 'plain.npz')
+    ts2.save(f2, compress=False)
+    back = core.CellTimeSeries.load(f2)
+    assert back.timesys == 'topocentric' and back.alt_starts is None
+    with pytest.raises(Exception):
+        back.get_bary_bins()

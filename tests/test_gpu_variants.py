@@ -185,3 +185,30 @@ def test_barycentred_cells_match_reference(golden, timeref, tag):
     assert np.allclose(n(ts.weights), g[tag + '_ts_weights'], rtol=1e-12, atol=1e-13)
     assert np.allclose(n(ts.weights2), g[tag + '_ts_weights2'], rtol=1e-12, atol=1e-13)
     assert ts.timesys == str(g[tag + '_ts_timesys']) == 'barycenter'
+
+
+@pytest.mark.parametrize('tag', ['all', 'part'])
+def test_photon_cells_match_reference(golden, tag, capsys):
+    """tcell=None: one cell per photon, boundaries at the exposure midpoints, cells
+    broken at gaps of the exposure table."""
+    g = golden('photon_cells.npz')
+    data = _data(g)
+    a, b = g[tag + '_range']
+    cells = data.get_photon_cells(a, b)
+    assert 'have %d photons' % len(g[tag + '_ti']) in capsys.readouterr().out
+    n = lambda x: x.cpu().numpy()
+    assert len(cells) == len(g[tag + '_starts'])
+    assert np.array_equal(n(cells.hi) - n(cells.lo), np.ones(len(cells), dtype=np.int64))
+    assert np.array_equal(n(cells.ti), g[tag + '_ti'])
+    assert np.array_equal(n(cells.we), g[tag + '_we'])
+    assert np.array_equal(n(cells.starts), g[tag + '_starts'])
+    assert np.array_equal(n(cells.stops), g[tag + '_stops'])
+    assert np.allclose(n(cells.sexp), g[tag + '_exp'], rtol=1e-12, atol=0)
+    assert np.allclose(n(cells.sexp / cells.bexp), g[tag + '_SonB'], rtol=1e-12, atol=0)
+    if tag == 'all':
+        via = data.get_cells(tcell=None, use_barycenter=False, quiet=True)
+        assert np.array_equal(n(via.starts), g['via_get_cells_starts'])
+    with pytest.raises(ValueError):
+        data.get_photon_cells(g['in_TSTART'][0] - 1.0, b)
+    with pytest.raises(ValueError):
+        data.get_photon_cells(a, g['in_TSTOP'][-1] + 1.0)

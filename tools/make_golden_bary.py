@@ -61,6 +61,11 @@ def main(outdir):
                         tag + '_ts_weights': ts.weights, tag + '_ts_weights2': ts.weights2,
                         tag + '_ts_alt_starts': ts.alt_starts, tag + '_ts_alt_stops': ts.alt_stops,
                         tag + '_ts_timesys': np.array(ts.timesys)})
+            if tag == 'topo':
+                # the interchange file between the binning and spectrum stages, as the
+                # reference writes it (CellTimeSeries.save, core.py:246-260)
+                os.makedirs(outdir, exist_ok=True)
+                ts.save(os.path.join(outdir, 'cell_timeseries_ref.npz'))
     os.makedirs(outdir, exist_ok=True)
     np.savez_compressed(os.path.join(outdir, 'bary_cells.npz'), **out)
     print('wrote', os.path.join(outdir, 'bary_cells.npz'), len(out), 'arrays')
