@@ -168,7 +168,7 @@ struct QuadStore {
 
 // numpy.cumsum adds left to right, and which cells end up with an exposure of
 // exactly zero (and are trimmed, core.py:2110-2122) depends on that rounding
-// order.  To reproduce it bit for bit the running sums are formed serially:
+// order.  Short tables: the running sums are formed serially, bit for bit:
 // four lanes of the first wavefront (one per series) walk a tile of the four
 // series in LDS carrying their running sum, sixteen elements per trip (the
 // chain of dependent fp64 additions is the floor: measured about 22 cycles
@@ -269,6 +269,329 @@ __global__ __launch_bounds__(SEQ_THREADS) void exposure_cumsum_kernel(ExposureLo
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same running sums, bit for bit, in parallel.
+//
+// While the running sum s stays inside one binade [2^k, 2^(k+1)) it is a
+// multiple S u of u = 2^(k-52), and fl(s + x) for x >= 0 is S u plus x rounded
+// to a multiple of u: an INTEGER addition S += rn(x / u), where only an exact
+// tie (x / u = X + 1/2) looks at S, through its parity (ties go to even).  An
+// element is therefore a map S -> S + (S even ? e : o), and such maps compose
+// into maps of the same form, so a chunk of rows reduces to one pair (e, o) and
+// can be scanned in parallel in exact integer arithmetic.
+//
+//   1. per chunk of 2048 rows: plain fp64 totals (estimates only);
+//   2. their prefix: an estimate of s at the start of every chunk, from which
+//      the binade k of the chunk is guessed;
+//   3. per chunk: the composed pair (e, o) for that k, or "irregular" (negative
+//      or non-finite x, no estimate);
+//   4. one workgroup per series walks the chunks with the exact s: a regular
+//      chunk is accepted if s really lies in binade k and the sum stays below
+//      2^(k+1) (x >= 0: then every partial sum does) and costs one integer
+//      addition; any other chunk is added row by row, as numpy does;
+//   5. per accepted chunk: the scan inside the chunk from its exact start.
+// A binade is crossed some forty times in a ten-year table, so all but a few
+// dozen chunks per series go the parallel way.
+// ---------------------------------------------------------------------------
+constexpr int CS_CHUNK = 2048;
+constexpr int CS_THREADS = 256;
+constexpr int CS_RPT = CS_CHUNK / CS_THREADS;
+constexpr int CS_INFO_TILE = 2048;          // chunk records staged in LDS per trip of the walk
+constexpr int CS_K_ANY = INT32_MIN;         // all-zero chunk: leaves any s unchanged
+constexpr int64_t CS_2P53 = (int64_t)1 << 53;
+
+struct Adder {
+    int64_t even, odd;                      // S -> S + (S even ? even : odd)
+};
+__device__ __forceinline__ Adder adder_then(const Adder &f, const Adder &g)   // f first, then g
+{
+    Adder h;
+    h.even = f.even + ((f.even & 1) ? g.odd : g.even);
+    h.odd = f.odd + (((f.odd + 1) & 1) ? g.odd : g.even);
+    return h;
+}
+__device__ __forceinline__ int64_t adder_apply(int64_t S, const Adder &f) { return S + ((S & 1) ? f.odd : f.even); }
+
+struct ChunkInfo {
+    int64_t even, odd;
+    int32_t k;
+    int32_t regular;
+};
+
+__device__ __forceinline__ double quad_get(const Quad &q, int c)
+{
+    return c == 0 ? q.a : (c == 1 ? q.b : (c == 2 ? q.c : q.d));
+}
+
+// x as an adder in units of u = 2^(k-52); false when x does not qualify
+__device__ __forceinline__ bool element_adder(double x, int k, Adder &f)
+{
+    if (!(x >= 0.0)) return false;
+    const double xs = ldexp(x, 52 - k);                 // exact: a power-of-two scaling
+    if (!(xs < 9007199254740992.0)) return false;
+    const double fl = floor(xs);
+    const double fr = xs - fl;                          // exact
+    const int64_t X0 = (int64_t)fl;
+    if (fr > 0.5) {
+        f.even = f.odd = X0 + 1;
+    } else if (fr < 0.5) {
+        f.even = f.odd = X0;
+    } else {                                            // tie: to the even sum
+        f.even = X0 + (X0 & 1);
+        f.odd = X0 + ((X0 & 1) ^ 1);
+    }
+    return true;
+}
+
+__device__ __forceinline__ Quad quad_block_sum(Quad v, Quad *sm)
+{
+    v.a = team_sum<WAVE>(v.a);
+    v.b = team_sum<WAVE>(v.b);
+    v.c = team_sum<WAVE>(v.c);
+    v.d = team_sum<WAVE>(v.d);
+    if (threadIdx.x % WAVE == 0) sm[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    Quad t = sm[0];
+    for (int q = 1; q < CS_THREADS / WAVE; ++q) t = t + sm[q];
+    __syncthreads();
+    return t;
+}
+
+// step 1
+__global__ __launch_bounds__(CS_THREADS) void cs_totals_kernel(ExposureLoad ld, int64_t n, Quad *totals)
+{
+    __shared__ Quad sm[CS_THREADS / WAVE];
+    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK;
+    Quad v{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < CS_RPT; ++j) {
+        const int64_t r = base + threadIdx.x + j * CS_THREADS;
+        if (r < n) v = v + ld(r);
+    }
+    v = quad_block_sum(v, sm);
+    if (threadIdx.x == 0) totals[blockIdx.x] = v;
+}
+
+// step 2: est[c] = sum of totals[0 .. c-1] (one workgroup)
+__global__ __launch_bounds__(1024) void cs_estimate_kernel(const Quad *totals, int64_t nchunk, Quad *est)
+{
+    __shared__ Quad part[1024];
+    const int64_t per = (nchunk + 1023) / 1024;
+    const int64_t c0 = (int64_t)threadIdx.x * per;
+    const int64_t c1 = c0 + per < nchunk ? c0 + per : nchunk;
+    Quad v{0, 0, 0, 0};
+    for (int64_t c = c0; c < c1; ++c) v = v + totals[c];
+    part[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Quad run{0, 0, 0, 0};
+        for (int t = 0; t < 1024; ++t) {
+            Quad nx = run + part[t];
+            part[t] = run;
+            run = nx;
+        }
+    }
+    __syncthreads();
+    v = part[threadIdx.x];
+    for (int64_t c = c0; c < c1; ++c) {
+        est[c] = v;
+        v = v + totals[c];
+    }
+}
+
+// step 3
+__global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, int64_t n, const Quad *est,
+                                                               ChunkInfo *info)
+{
+    __shared__ Adder sm[CS_THREADS];
+    __shared__ int sm_flag[2];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK + (int64_t)tid * CS_RPT;
+    Quad q[CS_RPT];
+#pragma unroll
+    for (int j = 0; j < CS_RPT; ++j) q[j] = (base + j < n) ? ld(base + j) : Quad{0, 0, 0, 0};
+    const Quad e = est[blockIdx.x];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double ec = quad_get(e, c);
+        const bool have_k = ec > 0.0 && ec < INFINITY;
+        const int k = have_k ? ilogb(ec) : 0;
+        Adder f{0, 0};
+        bool ok = true, allzero = true;
+#pragma unroll
+        for (int j = 0; j < CS_RPT; ++j) {
+            const double x = quad_get(q[j], c);
+            allzero = allzero && (x == 0.0);
+            Adder g{0, 0};
+            ok = ok && element_adder(x, k, g);
+            f = adder_then(f, g);
+        }
+        if (tid == 0) sm_flag[0] = sm_flag[1] = 1;
+        __syncthreads();
+        if (!ok) sm_flag[0] = 0;
+        if (!allzero) sm_flag[1] = 0;
+        sm[tid] = f;
+        __syncthreads();
+        for (int st = 1; st < CS_THREADS; st <<= 1) {
+            if ((tid & (2 * st - 1)) == 0) sm[tid] = adder_then(sm[tid], sm[tid + st]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            ChunkInfo ci;
+            if (sm_flag[1]) {
+                ci = ChunkInfo{0, 0, CS_K_ANY, 1};
+            } else {
+                const bool reg = have_k && sm_flag[0] && sm[0].even < CS_2P53 && sm[0].odd < CS_2P53 &&
+                                 sm[0].even >= 0 && sm[0].odd >= 0;
+                ci = ChunkInfo{sm[0].even, sm[0].odd, k, reg ? 1 : 0};
+            }
+            info[(int64_t)blockIdx.x * 4 + c] = ci;
+        }
+        __syncthreads();
+    }
+}
+
+// step 4: blockIdx.x = series
+__global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, int64_t n, int64_t nchunk,
+                                                             const ChunkInfo *info, double *entry, int32_t *by_walk,
+                                                             Quad *cum)
+{
+    __shared__ ChunkInfo s_info[CS_INFO_TILE];
+    __shared__ double s_x[CS_CHUNK];
+    __shared__ int64_t s_chunk;
+    const int tid = threadIdx.x, col = blockIdx.x;
+    double *cumd = (double *)cum;
+    double s = 0.0;                       // thread 0: the exact running sum
+    for (int64_t tile0 = 0; tile0 < nchunk; tile0 += CS_INFO_TILE) {
+        const int64_t tile1 = tile0 + CS_INFO_TILE < nchunk ? tile0 + CS_INFO_TILE : nchunk;
+        for (int64_t c = tile0 + tid; c < tile1; c += CS_THREADS) s_info[c - tile0] = info[c * 4 + col];
+        __syncthreads();
+        int64_t chunk = tile0;
+        while (true) {
+            if (tid == 0) {
+                // over the chunks that go the parallel way
+                while (chunk < tile1) {
+                    const ChunkInfo in = s_info[chunk - tile0];
+                    if (!in.regular) break;
+                    if (in.k == CS_K_ANY) {
+                        entry[chunk * 4 + col] = s;
+                        by_walk[chunk * 4 + col] = 0;
+                        ++chunk;
+                        continue;
+                    }
+                    if (!(s > 0.0) || ilogb(s) != in.k) break;
+                    const int64_t S = (int64_t)ldexp(s, 52 - in.k);
+                    const int64_t S2 = adder_apply(S, Adder{in.even, in.odd});
+                    if (S2 >= CS_2P53) break;
+                    entry[chunk * 4 + col] = s;
+                    by_walk[chunk * 4 + col] = 0;
+                    s = ldexp((double)S2, in.k - 52);
+                    ++chunk;
+                }
+                s_chunk = chunk;
+            }
+            __syncthreads();
+            chunk = s_chunk;
+            if (chunk >= tile1) break;
+            // this chunk row by row: everyone fetches, thread 0 adds, everyone stores
+            const int64_t base = chunk * CS_CHUNK;
+            const int m = (int)((n - base) < CS_CHUNK ? (n - base) : CS_CHUNK);
+#pragma unroll
+            for (int j = 0; j < CS_RPT; ++j) {
+                const int r = tid + j * CS_THREADS;
+                s_x[r] = (r < m) ? quad_get(ld(base + r), col) : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double a[16];
+                for (int r0 = 0; r0 < CS_CHUNK; r0 += 16) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a[u] = s_x[r0 + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        s = __dadd_rn(s, a[u]);
+                        a[u] = s;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) s_x[r0 + u] = a[u];
+                    if (r0 + 16 >= m) break;
+                }
+                // rows past the end of the table were zeros: s is the sum of the m rows
+                s = s_x[m - 1];
+                by_walk[chunk * 4 + col] = 1;
+            }
+            __syncthreads();
+            for (int r = tid; r < m; r += CS_THREADS) cumd[(base + r) * 4 + col] = s_x[r];
+            ++chunk;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+// step 5
+__global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, int64_t n, const ChunkInfo *info,
+                                                             const double *entry, const int32_t *by_walk,
+                                                             Quad *cum)
+{
+    __shared__ Adder sm[2][CS_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK + (int64_t)tid * CS_RPT;
+    double *cumd = (double *)cum;
+    Quad q[CS_RPT];
+#pragma unroll
+    for (int j = 0; j < CS_RPT; ++j) q[j] = (base + j < n) ? ld(base + j) : Quad{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t ic = (int64_t)blockIdx.x * 4 + c;
+        if (by_walk[ic]) continue;                    // uniform over the workgroup
+        const ChunkInfo in = info[ic];
+        const double s0 = entry[ic];
+        if (in.k == CS_K_ANY) {
+#pragma unroll
+            for (int j = 0; j < CS_RPT; ++j)
+                if (base + j < n) cumd[(base + j) * 4 + c] = s0;
+            continue;
+        }
+        Adder g[CS_RPT];
+        Adder f{0, 0};
+#pragma unroll
+        for (int j = 0; j < CS_RPT; ++j) {
+            g[j] = Adder{0, 0};
+            element_adder(quad_get(q[j], c), in.k, g[j]);
+            f = adder_then(f, g[j]);
+        }
+        // inclusive scan of the threads' adders (Hillis-Steele, order kept)
+        int cur = 0;
+        sm[0][tid] = f;
+        __syncthreads();
+        for (int off = 1; off < CS_THREADS; off <<= 1) {
+            Adder v = sm[cur][tid];
+            if (tid >= off) v = adder_then(sm[cur][tid - off], v);
+            sm[cur ^ 1][tid] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        int64_t S = (int64_t)ldexp(s0, 52 - in.k);
+        if (tid > 0) S = adder_apply(S, sm[cur][tid - 1]);
+#pragma unroll
+        for (int j = 0; j < CS_RPT; ++j) {
+            S = adder_apply(S, g[j]);
+            if (base + j < n) cumd[(base + j) * 4 + c] = ldexp((double)S, in.k - 52);
+        }
+        __syncthreads();
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int64_t cs_chunks(int64_t n) { return (n + CS_CHUNK - 1) / CS_CHUNK; }
+inline size_t cs_scratch_bytes(int64_t n)
+{
+    const size_t nc = (size_t)cs_chunks(n);
+    return 2 * align256(sizeof(Quad) * nc) + align256(sizeof(ChunkInfo) * 4 * nc) +
+           align256(sizeof(double) * 4 * nc) + align256(sizeof(int32_t) * 4 * nc);
+}
+
 // cumulative exposures at the query times: core.py:1806-1832
 __global__ void exposure_query_kernel(ExposureLoad ld, const Quad *cum, int64_t n_ft2, const double *times,
                                       int64_t n_t, Quad *at)
@@ -339,7 +662,6 @@ __global__ void gather_kernel(const T *src, const int64_t *idx, int64_t n, T *ds
     if (k < n) dst[k] = src[idx[k]];
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // numpy.searchsorted(a, v, side): out[k] = first index with a[i] >= v[k] (left) or > v[k] (right)
 __global__ void search_sorted_kernel(const double *a, int64_t n, const double *v, int64_t nv, int right,
@@ -380,8 +702,34 @@ int exposure_table_impl(const ExposureLoad &ld, int64_t n_ft2, void *table, size
                   "%s: null table pointer", fn);
     GODOT_REQUIRE(table && table_bytes >= align256(sizeof(Quad) * (size_t)n_ft2), GODOT_E_WORKSPACE,
                   "%s: table smaller than godot_exposure_table_bytes(n_ft2)", fn);
-    hipLaunchKernelGGL(exposure_cumsum_kernel, dim3(1), dim3(SEQ_THREADS), 0, (hipStream_t)stream, ld, n_ft2,
-                       (Quad *)table);
+    hipStream_t st = (hipStream_t)stream;
+    Quad *cum = (Quad *)table;
+    const size_t tsz = align256(sizeof(Quad) * (size_t)n_ft2);
+    if (n_ft2 < 4 * CS_CHUNK || table_bytes < tsz + cs_scratch_bytes(n_ft2)) {
+        // short tables (or a caller that sized the table for the sums alone): one workgroup, serially
+        hipLaunchKernelGGL(exposure_cumsum_kernel, dim3(1), dim3(SEQ_THREADS), 0, st, ld, n_ft2, cum);
+        GODOT_LAUNCH_CHECK(fn);
+        return GODOT_OK;
+    }
+    const int64_t nc = cs_chunks(n_ft2);
+    char *w = (char *)table + tsz;
+    Quad *totals = (Quad *)w;
+    w += align256(sizeof(Quad) * (size_t)nc);
+    Quad *est = (Quad *)w;
+    w += align256(sizeof(Quad) * (size_t)nc);
+    ChunkInfo *info = (ChunkInfo *)w;
+    w += align256(sizeof(ChunkInfo) * 4 * (size_t)nc);
+    double *entry = (double *)w;
+    w += align256(sizeof(double) * 4 * (size_t)nc);
+    int32_t *by_walk = (int32_t *)w;
+    hipLaunchKernelGGL(cs_totals_kernel, dim3((unsigned)nc), dim3(CS_THREADS), 0, st, ld, n_ft2, totals);
+    hipLaunchKernelGGL(cs_estimate_kernel, dim3(1), dim3(1024), 0, st, (const Quad *)totals, nc, est);
+    hipLaunchKernelGGL(cs_adders_kernel, dim3((unsigned)nc), dim3(CS_THREADS), 0, st, ld, n_ft2, (const Quad *)est,
+                       info);
+    hipLaunchKernelGGL(cs_walk_kernel, dim3(4), dim3(CS_THREADS), 0, st, ld, n_ft2, nc, (const ChunkInfo *)info,
+                       entry, by_walk, cum);
+    hipLaunchKernelGGL(cs_fill_kernel, dim3((unsigned)nc), dim3(CS_THREADS), 0, st, ld, n_ft2,
+                       (const ChunkInfo *)info, (const double *)entry, (const int32_t *)by_walk, cum);
     GODOT_LAUNCH_CHECK(fn);
     return GODOT_OK;
 }
@@ -413,7 +761,8 @@ int exposure_at_impl(const ExposureLoad &ld, int64_t n_ft2, const void *table, c
 
 extern "C" size_t godot_exposure_table_bytes(int64_t n_ft2)
 {
-    return n_ft2 < 0 ? 0 : align256(sizeof(Quad) * (size_t)n_ft2);
+    // the running sums, then the per-chunk records of the parallel scan
+    return n_ft2 < 0 ? 0 : align256(sizeof(Quad) * (size_t)n_ft2) + cs_scratch_bytes(n_ft2);
 }
 
 extern "C" int godot_exposure_table(const double *tstart, const double *tstop, const double *exposure,

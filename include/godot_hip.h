@@ -158,8 +158,10 @@ int godot_cell_logpdf_profile(const double *we, int64_t nph,
  * four series exposure, (S/E) exposure, (B/E) exposure and dead time
  * (TSTOP-TSTART)-LIVETIME, added left to right exactly as numpy does so that
  * differences of the sums (and therefore the zero-exposure trimming mask) are
- * bit-identical to the reference's.  `table` (device, godot_exposure_table_bytes
- * bytes) depends only on the exposure table and the two scale factors: build it
+ * bit-identical to the reference's (long tables are summed in parallel with
+ * the sequential result's own roundings).  `table` (device,
+ * godot_exposure_table_bytes bytes: the sums followed by scratch of the build)
+ * depends only on the exposure table and the two scale factors: build it
  * once, reuse it for every godot_exposure_at call.                            */
 size_t godot_exposure_table_bytes(int64_t n_ft2);
 int godot_exposure_table(const double *tstart, const double *tstop,

@@ -9,6 +9,7 @@ from oracle import godot_oracle as orc
 from conftest import assert_same
 
 pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
 
 
 def _data(g):
@@ -111,3 +112,65 @@ def test_large_binning_matches_oracle_and_conserves_photons():
     assert_same(_n(cells.bexp), b['bexp'], "b['bexp']")
     ts = d.get_cells(tcell=600., use_barycenter=False, time_series_only=True, trim_zero_exposure=False)
     assert int(_n(ts.counts).sum()) == np.searchsorted(s['ti'], _n(ts.stops)[-1]) - np.searchsorted(s['ti'], _n(ts.starts)[0])
+
+
+def _table_columns(x1, x4, s_over_e, b_over_e):
+    """Running sums of the four series through godot_exposure_table: exposure x1,
+    its two multiples, and x4 as the dead time (TSTART = LIVETIME = 0, TSTOP = x4)."""
+    from godot_amd import ops
+    n = len(x1)
+    z = torch.zeros(n, dtype=torch.float64, device=DEV)
+    table = ops.exposure_table(z, torch.from_numpy(x4).to(DEV), torch.from_numpy(x1).to(DEV), z.clone(),
+                               s_over_e, b_over_e)
+    torch.cuda.synchronize()
+    return table[:32 * n].view(torch.float64).view(n, 4).cpu().numpy()
+
+
+def _same_bits(a, b):
+    return np.array_equal(a.view(np.int64), b.view(np.int64))
+
+
+@pytest.mark.parametrize('case', ['realistic', 'ties', 'zeros', 'range', 'negative', 'short', 'nan'])
+def test_running_sums_are_numpy_cumsum_bit_for_bit(case):
+    """The parallel form of the running sums (integer scan inside a binade,
+    parity-dependent ties) must give numpy.cumsum's left-to-right result exactly."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n = 150_001
+    se, be = 0.173, 0.827
+    if case == 'realistic':
+        x1 = 27 * (3000 + 2000 * np.sin(np.arange(n) * 0.033) ** 2)
+        x4 = np.full(n, 3.0)
+    elif case == 'ties':
+        # x1: odd multiples of 2^-14 (+ 2^22): every addition is an exact tie once s is in
+        # [2^39, 2^40), u = 2^-13, from row 131072 on; x4: odd multiples of 2^-30 onto
+        # s = 2^23 (u = 2^-29): ties from the second row on, s never leaves the binade
+        x1 = (2 * rng.integers(0, 1 << 30, n) + 1) * 2.0 ** -14 + 2.0 ** 22
+        x4 = (2 * rng.integers(0, 8, n) + 1) * 2.0 ** -30
+        x4[0] = 2.0 ** 23
+        assert 2.0 ** 39 < np.sum(x1[:140000]) < np.sum(x1) < 2.0 ** 40
+    elif case == 'zeros':
+        x1 = np.where(rng.random(n) < 0.7, 0.0, rng.uniform(0, 1e5, n))
+        x1[:5000] = 0.0
+        x4 = np.zeros(n)
+    elif case == 'range':
+        x1 = 10.0 ** rng.uniform(-12, 9, n)
+        x4 = 2.0 ** rng.integers(-40, 30, n).astype(np.float64)
+    elif case == 'negative':
+        x1 = rng.uniform(0, 1e5, n)
+        x4 = rng.normal(0.0, 1.0, n)
+        x4[::3] = np.abs(x4[::3])
+    elif case == 'short':
+        n = 5000
+        x1 = rng.uniform(0, 1e5, n)
+        x4 = rng.uniform(0, 3, n)
+    else:
+        n = 20_000
+        x1 = rng.uniform(0, 1e5, n)
+        x1[12345] = np.nan
+        x4 = rng.uniform(0, 3, n)
+        x4[777] = np.inf
+    got = _table_columns(x1, x4, se, be)
+    with np.errstate(all='ignore'):
+        want = [np.cumsum(x1), np.cumsum(se * x1), np.cumsum(be * x1), np.cumsum((x4 - 0.0) - 0.0)]
+    for c in range(4):
+        assert _same_bits(got[:, c], want[c]), (case, c, int(np.argmax(got[:, c].view(np.int64) != want[c].view(np.int64))))
