@@ -399,17 +399,38 @@ __global__ __launch_bounds__(1024) void cs_estimate_kernel(const Quad *totals, i
     }
 }
 
+// A chunk of the four series in LDS, one padded row of doubles per series: filled
+// with coalesced loads (consecutive lanes, consecutive rows), read back by the
+// thread that owns CS_RPT consecutive rows.  One spare slot per 8 rows keeps those
+// reads (stride 8 rows across lanes) off a common bank.
+constexpr int CS_PAD = CS_CHUNK + CS_CHUNK / 8;
+__device__ __forceinline__ int cs_slot(int r) { return r + (r >> 3); }
+
+__device__ __forceinline__ void cs_stage_chunk(const ExposureLoad &ld, int64_t base, int64_t n,
+                                               double (&s_v)[4][CS_PAD])
+{
+#pragma unroll
+    for (int j = 0; j < CS_RPT; ++j) {
+        const int r = threadIdx.x + j * CS_THREADS;
+        const Quad q = (base + r < n) ? ld(base + r) : Quad{0, 0, 0, 0};
+        const int o = cs_slot(r);
+        s_v[0][o] = q.a;
+        s_v[1][o] = q.b;
+        s_v[2][o] = q.c;
+        s_v[3][o] = q.d;
+    }
+    __syncthreads();
+}
+
 // step 3
 __global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, int64_t n, const Quad *est,
                                                                ChunkInfo *info)
 {
+    __shared__ double s_v[4][CS_PAD];
     __shared__ Adder sm[CS_THREADS];
     __shared__ int sm_flag[2];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK + (int64_t)tid * CS_RPT;
-    Quad q[CS_RPT];
-#pragma unroll
-    for (int j = 0; j < CS_RPT; ++j) q[j] = (base + j < n) ? ld(base + j) : Quad{0, 0, 0, 0};
+    cs_stage_chunk(ld, (int64_t)blockIdx.x * CS_CHUNK, n, s_v);
     const Quad e = est[blockIdx.x];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, 
         bool ok = true, allzero = true;
 #pragma unroll
         for (int j = 0; j < CS_RPT; ++j) {
-            const double x = quad_get(q[j], c);
+            const double x = s_v[c][cs_slot(tid * CS_RPT + j)];
             allzero = allzero && (x == 0.0);
             Adder g{0, 0};
             ok = ok && element_adder(x, k, g);
@@ -451,14 +472,19 @@ __global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, 
     }
 }
 
-// step 4: blockIdx.x = series
+// step 4: blockIdx.x = series.  The exact sum s is carried as its bit pattern:
+// for s in binade k the integer S = s / u is the significand with its leading
+// bit, so entering and leaving a regular chunk is integer work only.
 __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, int64_t n, int64_t nchunk,
                                                              const ChunkInfo *info, double *entry, int32_t *by_walk,
                                                              Quad *cum)
 {
     __shared__ ChunkInfo s_info[CS_INFO_TILE];
+    __shared__ double s_entry[CS_INFO_TILE];
+    __shared__ int32_t s_by[CS_INFO_TILE];
     __shared__ double s_x[CS_CHUNK];
     __shared__ int64_t s_chunk;
+    constexpr int64_t MANT = ((int64_t)1 << 52) - 1;
     const int tid = threadIdx.x, col = blockIdx.x;
     double *cumd = (double *)cum;
     double s = 0.0;                       // thread 0: the exact running sum
@@ -470,24 +496,26 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
         while (true) {
             if (tid == 0) {
                 // over the chunks that go the parallel way
+                int64_t bits = __double_as_longlong(s);
                 while (chunk < tile1) {
                     const ChunkInfo in = s_info[chunk - tile0];
                     if (!in.regular) break;
-                    if (in.k == CS_K_ANY) {
-                        entry[chunk * 4 + col] = s;
-                        by_walk[chunk * 4 + col] = 0;
-                        ++chunk;
-                        continue;
+                    if (in.k != CS_K_ANY) {
+                        // s positive, finite, normal and in binade k <=> sign 0, biased exponent k + 1023
+                        const int64_t ex = bits >> 52;
+                        if (ex != (int64_t)in.k + 1023 || ex <= 0 || ex >= 2047) break;
+                        const int64_t S = (bits & MANT) | (MANT + 1);
+                        const int64_t S2 = adder_apply(S, Adder{in.even, in.odd});
+                        if (S2 >= CS_2P53) break;
+                        s_entry[chunk - tile0] = __longlong_as_double(bits);
+                        bits = (ex << 52) | (S2 & MANT);
+                    } else {
+                        s_entry[chunk - tile0] = __longlong_as_double(bits);
                     }
-                    if (!(s > 0.0) || ilogb(s) != in.k) break;
-                    const int64_t S = (int64_t)ldexp(s, 52 - in.k);
-                    const int64_t S2 = adder_apply(S, Adder{in.even, in.odd});
-                    if (S2 >= CS_2P53) break;
-                    entry[chunk * 4 + col] = s;
-                    by_walk[chunk * 4 + col] = 0;
-                    s = ldexp((double)S2, in.k - 52);
+                    s_by[chunk - tile0] = 0;
                     ++chunk;
                 }
+                s = __longlong_as_double(bits);
                 s_chunk = chunk;
             }
             __syncthreads();
@@ -518,12 +546,18 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
                 }
                 // rows past the end of the table were zeros: s is the sum of the m rows
                 s = s_x[m - 1];
-                by_walk[chunk * 4 + col] = 1;
+                s_by[chunk - tile0] = 1;
+                s_entry[chunk - tile0] = 0.0;
             }
             __syncthreads();
             for (int r = tid; r < m; r += CS_THREADS) cumd[(base + r) * 4 + col] = s_x[r];
             ++chunk;
             __syncthreads();
+        }
+        __syncthreads();
+        for (int64_t c = tile0 + tid; c < tile1; c += CS_THREADS) {
+            entry[c * 4 + col] = s_entry[c - tile0];
+            by_walk[c * 4 + col] = s_by[c - tile0];
         }
         __syncthreads();
     }
@@ -534,23 +568,22 @@ __global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, in
                                                              const double *entry, const int32_t *by_walk,
                                                              Quad *cum)
 {
+    __shared__ double s_v[4][CS_PAD];
     __shared__ Adder sm[2][CS_THREADS];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK + (int64_t)tid * CS_RPT;
-    double *cumd = (double *)cum;
-    Quad q[CS_RPT];
-#pragma unroll
-    for (int j = 0; j < CS_RPT; ++j) q[j] = (base + j < n) ? ld(base + j) : Quad{0, 0, 0, 0};
+    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK;
+    cs_stage_chunk(ld, base, n, s_v);
+    int done = 0;                                     // series whose sums now stand in s_v
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int64_t ic = (int64_t)blockIdx.x * 4 + c;
         if (by_walk[ic]) continue;                    // uniform over the workgroup
+        done |= 1 << c;
         const ChunkInfo in = info[ic];
         const double s0 = entry[ic];
         if (in.k == CS_K_ANY) {
 #pragma unroll
-            for (int j = 0; j < CS_RPT; ++j)
-                if (base + j < n) cumd[(base + j) * 4 + c] = s0;
+            for (int j = 0; j < CS_RPT; ++j) s_v[c][cs_slot(tid * CS_RPT + j)] = s0;
             continue;
         }
         Adder g[CS_RPT];
@@ -558,7 +591,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, in
 #pragma unroll
         for (int j = 0; j < CS_RPT; ++j) {
             g[j] = Adder{0, 0};
-            element_adder(quad_get(q[j], c), in.k, g[j]);
+            element_adder(s_v[c][cs_slot(tid * CS_RPT + j)], in.k, g[j]);
             f = adder_then(f, g[j]);
         }
         // inclusive scan of the threads' adders (Hillis-Steele, order kept)
@@ -577,9 +610,25 @@ __global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, in
 #pragma unroll
         for (int j = 0; j < CS_RPT; ++j) {
             S = adder_apply(S, g[j]);
-            if (base + j < n) cumd[(base + j) * 4 + c] = ldexp((double)S, in.k - 52);
+            s_v[c][cs_slot(tid * CS_RPT + j)] = ldexp((double)S, in.k - 52);
         }
         __syncthreads();
+    }
+    __syncthreads();
+    // out in whole rows when all four series were scanned here, else series by series
+    double *cumd = (double *)cum;
+#pragma unroll
+    for (int j = 0; j < CS_RPT; ++j) {
+        const int r = tid + j * CS_THREADS;
+        if (base + r >= n) continue;
+        const int o = cs_slot(r);
+        if (done == 15) {
+            cum[base + r] = Quad{s_v[0][o], s_v[1][o], s_v[2][o], s_v[3][o]};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (done & (1 << c)) cumd[(base + r) * 4 + c] = s_v[c][o];
+        }
     }
 }
 
