@@ -59,6 +59,22 @@ class CellRanges(object):
     def _head(self):
         return (_p(self.we), self.nph, _p(self.lo), _p(self.hi))
 
+    def shard(self, c0, c1):
+        """Cells [c0, c1) as a view of their own: the weights are narrowed to the
+        photons those cells can reach and the ranges shifted accordingly.  The
+        kernels choose their shape from photons per cell, which they take from
+        the length of the weight array, so a rank should hand over its slice and
+        not the whole list.  One device-to-host read."""
+        lo, hi = self.lo[c0:c1], self.hi[c0:c1]
+        if lo.numel() == 0:
+            return CellRanges(self.we[:0], lo.contiguous(), hi.contiguous(), self.S[c0:c1].contiguous(),
+                              None if self.B is None else self.B[c0:c1].contiguous())
+        a, b = (int(x) for x in torch.stack([lo.min(), hi.max()]).cpu())
+        a = min(max(a, 0), self.nph)
+        b = min(max(b, a), self.nph)
+        return CellRanges(self.we[a:b], (lo - a).contiguous(), (hi - a).contiguous(),
+                          self.S[c0:c1].contiguous(), None if self.B is None else self.B[c0:c1].contiguous())
+
 
 def _per_cell(x, n, dev, name):
     """Scalar -> (None, scalar); tensor -> (tensor, 0.0)."""

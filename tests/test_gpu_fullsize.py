@@ -1,0 +1,174 @@
+"""The hot path at the sizes the headline numbers are quoted on, checked
+through properties that do not need the (slow) oracle on every unit:
+conservation of photons, the maximum property of the fitted flux, TS from
+the likelihood differences, invariance under splitting the job, additivity
+of the trig sums, plus oracle spot checks on a few hundred units."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import godot_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+RTOL = 1e-9
+
+
+def _n(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def c2():
+    """10^7 photons over ten years in 600-s cells (5.26e5 cells, 4.4e5 of them with exposure)."""
+    from godot_amd import core, synth
+    s = synth.synth(10_000_000, years=10.0, seed=11)
+    data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=DEV)
+    cells = data.get_cells(tcell=600.0, use_barycenter=False, quiet=True)
+    return s, data, cells
+
+
+def test_c2_binning_conserves_photons_and_orders_cells(c2):
+    s, data, cells = c2
+    lo, hi = _n(cells.lo), _n(cells.hi)
+    assert len(lo) > 400_000
+    assert (hi >= lo).all() and (lo[1:] >= hi[:-1]).all()
+    starts, stops = _n(cells.starts), _n(cells.stops)
+    assert (stops > starts).all() and (starts[1:] >= stops[:-1]).all()
+    assert (_n(cells.sexp) > 0).all() and (_n(cells.bexp) > 0).all()
+    # every photon inside a kept cell is in that cell, and only those
+    ti = s['ti']
+    inside = np.zeros(len(ti), dtype=bool)
+    cell_of = np.searchsorted(stops, ti)            # photon on an edge -> earlier cell
+    ok = cell_of < len(stops)
+    inside[ok] = ti[ok] > starts[cell_of[ok]]
+    # the first cell also owns a photon exactly on its start
+    assert int((hi - lo).sum()) in (int(inside.sum()), int(inside.sum()) + int((ti == starts[0]).sum()))
+    pick = np.random.default_rng(0).choice(len(lo), 2000, replace=False)
+    for c in pick:
+        t = ti[lo[c]:hi[c]]
+        assert ((t > starts[c]) | (c == 0)).all() and (t <= stops[c]).all()
+    # summed exposure of the cells = exposure of the span they cover, to rounding
+    tot = _n(data.get_exposure(torch.tensor([s['TSTART'][0], stops[-1]], dtype=torch.float64, device=DEV))[1])
+    assert abs(_n(cells.sexp).sum() - (tot[1] - tot[0])) <= 1e-9 * tot[1]
+
+
+def test_c2_fit_is_the_maximum_and_ts_is_the_likelihood_ratio(c2):
+    from godot_amd import ops
+    s, data, cells = c2
+    cr = cells.ranges()
+    alpha, ts, flags = ops.cell_fit(cr)
+    a, t, fl = _n(alpha), _n(ts), _n(flags)
+    assert not (fl & 0x10).any()
+    assert np.isfinite(a).all() and (a >= 0).all() and np.isfinite(t).all()
+    assert ((fl & 1) != 0).sum() == (a == 0).sum()
+    # maximum property: logL(alpha_hat) >= logL(alpha_hat (1 +- 1e-3)) (the reference's own
+    # schedule stops within ~1e-6 of the root, far inside the perturbation)
+    l0 = _n(ops.cell_loglike(cr, alpha))
+    for f in (1 - 1e-3, 1 + 1e-3):
+        l1 = _n(ops.cell_loglike(cr, alpha * f))
+        assert (l0 - l1 >= -1e-9 * np.maximum(1.0, np.abs(l0)))[a > 0].all()
+    # boundary cells: the likelihood falls from alpha = 0
+    lz = _n(ops.cell_loglike(cr, torch.zeros_like(alpha)))
+    le = _n(ops.cell_loglike(cr, torch.full_like(alpha, 1e-3)))
+    assert (lz >= le)[a == 0].all()
+    # TS = 2 (logL(alpha_hat) - logL(0)), 0 on the boundary
+    cnt = _n(cr.hi - cr.lo)
+    scale = np.maximum(1.0, np.abs(lz))
+    assert (np.abs(t - 2 * (l0 - lz)) <= RTOL * scale)[a > 0].all()
+    assert (t[a == 0] == 0).all()
+    # oracle on a few hundred cells, restarted ones included
+    rng = np.random.default_rng(5)
+    depth = (fl >> 1) & 3
+    pick = np.unique(np.concatenate([rng.choice(len(a), 300, replace=False), np.flatnonzero(depth > 0)[:100],
+                                     np.argsort(cnt)[-20:]]))
+    we = s['we']
+    lo, hi, S, B = _n(cr.lo), _n(cr.hi), _n(cr.S), _n(cr.B)
+    wdev = _n(cr.we) if cr.we.numel() < 2 ** 27 else None
+    with np.errstate(all='ignore'):
+        for c in pick:
+            w = wdev[lo[c]:hi[c]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            ar = cl.get_max()
+            tr = cl.get_ts(ar)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            assert abs(a[c] - ar) <= RTOL * max(1, abs(ar)), (c, a[c], ar)
+            assert abs(t[c] - tr) <= RTOL * max(sc, abs(tr)), (c, t[c], tr)
+
+
+def test_c2_fit_does_not_depend_on_how_the_job_is_split(c2):
+    """Cell ranges fitted on their own (what a rank does, on its own slice of the
+    photons) reproduce the whole job: no cell sees its neighbours.  The kernel
+    shape follows the shard's occupancy, so sums may be grouped differently:
+    agreement to 1e-12, and to the bit for all but a few cells."""
+    from godot_amd import ops
+    from godot_amd import dist as gd
+    s, data, cells = c2
+    cr = cells.ranges()
+    alpha, ts, flags = ops.cell_fit(cr)
+    counts = _n(cr.hi - cr.lo)
+    a, t = _n(alpha), _n(ts)
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            c0, c1 = gd.cell_shard(counts, r, world)
+            sub = cr.shard(c0, c1)
+            assert sub.nph == int(counts[c0:c1].sum()) or sub.nph >= int(counts[c0:c1].sum())
+            parts.append(ops.cell_fit(sub))
+        a2 = _n(torch.cat([p[0] for p in parts]))
+        t2 = _n(torch.cat([p[1] for p in parts]))
+        f2 = _n(torch.cat([p[2] for p in parts]))
+        assert np.abs(a2 - a).max() <= 1e-12 * max(1.0, np.abs(a).max())
+        assert (np.abs(t2 - t) <= 1e-10 * np.maximum(1.0, np.abs(t))).all()
+        assert ((f2 & 1) == (_n(flags) & 1)).all()
+        assert (a2 == a).mean() > 0.99
+
+
+def test_c2_profile_grid_brackets_the_maximum(c2):
+    """a6 at full size: every profile peaks at 0 (within the reference's 0.05
+    acceptance), is 0 at the fitted flux, and falls to about -dlogl at its ends."""
+    from godot_amd import ops
+    s, data, cells = c2
+    cr = cells.ranges()
+    alpha, _, _ = ops.cell_fit(cr)
+    n = 200_000                         # 200k cells x 200 points x 2 arrays = 640 MB
+    sub = ops.CellRanges(cr.we, cr.lo[:n].contiguous(), cr.hi[:n].contiguous(), cr.S[:n].contiguous(),
+                         cr.B[:n].contiguous())
+    dom, cod, fl = ops.cell_logpdf(sub, dlogl=30, npt=200)
+    assert not (_n(fl) & 0x10).any()
+    top = cod.max(dim=1).values
+    assert bool((top.abs() <= 0.05).all())
+    assert bool((dom[:, 1:] > dom[:, :-1]).all()) and bool((dom[:, 0] >= 0).all())
+    a = alpha[:n]
+    inside = (a >= dom[:, 0]) & (a <= dom[:, -1])
+    assert bool(inside.all())
+    # right end: the search stops within 0.1 of -dlogl (reference core.py:869-916) after at most
+    # 5 steps; nearly all cells get there
+    right = _n(cod[:, -1])
+    assert np.median(np.abs(right + 30)) < 0.1 and (right < -20).mean() > 0.999
+
+
+def test_c4_trig_sums_add_and_match_the_oracle_at_spot_frequencies():
+    """10^6 photons x 2^21 frequencies: sums of photon shards add up to the whole
+    search; 12 random frequencies against the oracle's exactly reduced phases."""
+    from godot_amd import ops, synth
+    s = synth.synth(1_000_000, years=10.0, seed=17)
+    t, w = s['ti'] - s['ti'][0], s['we']
+    td, wd = torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV)
+    nf = 1 << 21
+    f0, df = 1e-4, 1.0 / (4 * (t[-1] - t[0]))
+    z, h = ops.z2m(td, wd, f0, df, nf, m=2, want_h=True)
+    zn = _n(z)
+    assert np.isfinite(zn).all() and (zn >= 0).all()
+    assert bool((h <= z).all()) and bool((h >= z - 4).all())      # H = max(Z1, Z2 - 4)
+    js = np.random.default_rng(3).choice(nf, 12, replace=False)
+    for j in js:
+        ref = orc.z2m(t, w, f0, df, 1, m=2, j0=int(j))[0]
+        assert abs(zn[j] - ref) <= 1e-10 * max(1.0, ref), (j, zn[j], ref)
+    # two photon shards, one frequency tile
+    j0, n = 777_000, 4096
+    cut = 400_000
+    s1, q1 = ops.z2m_sums(td[:cut].contiguous(), wd[:cut].contiguous(), f0, df, n, m=2, j0=j0)
+    s2, q2 = ops.z2m_sums(td[cut:].contiguous(), wd[cut:].contiguous(), f0, df, n, m=2, j0=j0)
+    zz, _ = ops.z2m_finish(s1 + s2, q1 + q2)
+    assert np.abs(_n(zz) - zn[j0:j0 + n]).max() <= 1e-10 * max(1.0, zn[j0:j0 + n].max())
