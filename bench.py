@@ -118,7 +118,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    # GODOT_BENCH_FORCE_DIST=1: take the multi-rank path with a single rank too (a rehearsal
+    # of the collectives on a one-GPU box)
+    if world > 1 or os.environ.get('GODOT_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world,
@@ -189,6 +191,39 @@ def main():
         elapsed = float(tmax[0].cpu())
     total_cells = float(tot[1].cpu())
 
+    # ---- the second half of the metric across the ranks: one Z^2_2 search, trial
+    # frequencies sharded (2^21 per rank), photons replicated, global maximum gathered
+    z2_all = None
+    if dist is not None and not args.no_extra:
+        from godot_amd import dist as gd
+        zs = synth.synth(1_000_000, years=1.0, seed=17)
+        zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
+        zw = torch.from_numpy(zs['we']).to(dev)
+        nf_all = (1 << 21) * world
+        zspan = float(zs['ti'][-1] - zs['ti'][0])
+        zf0, zdf = 1e-4, 1.0 / (4 * zspan)
+        zws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), 1 << 21, 2), dtype=torch.uint8,
+                          device=dev)
+
+        def search_fn(j0, n):
+            return ops.z2m(zt, zw, zf0, zdf, n, m=2, j0=j0, workspace=zws)[0]
+
+        gd.search_sharded(nf_all, search_fn)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        zmax, jmax, _ = gd.search_sharded(nf_all, search_fn)
+        torch.cuda.synchronize()
+        barrier()
+        zt_s = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(zt_s, op=dist.ReduceOp.MAX)
+        z_s = float(zt_s[0].cpu())
+        z2_all = dict(photon_freq_evals_per_s=float(zt.numel()) * nf_all / z_s, s=z_s, nph=zt.numel(),
+                      nfreq=nf_all, m=2, n_gpus=world, z2_max=zmax, argmax=jmax,
+                      sharding='frequencies; photons replicated; all-gather of per-rank maxima')
+        del zws
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -212,6 +247,8 @@ def main():
 
     extra = dict(ncell=ncell, photons_in_cells=nph_in,
                  binning_first_call_s=t_bin_first, binning_cached_table_s=t_bin_again)
+    if z2_all is not None:
+        extra['z2m_all_gpus'] = z2_all
     if not args.no_extra:
         # 200-point profile grid on the same cells (FP64-ALU bound)
         ops.cell_logpdf(cr, dlogl=30, npt=200)
