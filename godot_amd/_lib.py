@@ -82,6 +82,8 @@ SIGNATURES = {
     'godot_z2m_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'godot_z2m': (c_int, [c_f64p, c_f64p, c_i64, c_f64, c_f64, c_i64, c_i64, c_int, c_f64p, c_f64p,
                           c_ws, c_size, c_stream]),
+    'godot_cell_sums': (c_int, [c_f64p, c_i64, c_i64p, c_i64p, c_i64, c_f64p, c_f64, c_f64p, c_f64, c_int,
+                                c_f64p, c_stream]),
     'godot_z2m_sums': (c_int, [c_f64p, c_f64p, c_i64, c_f64, c_f64, c_i64, c_i64, c_int, c_f64p, c_f64p,
                                c_ws, c_size, c_stream]),
     'godot_z2m_finish': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_f64p, c_f64p, c_stream]),

@@ -429,6 +429,141 @@ class CellLogLikelihood(object):
         self._last_beta = _scalar(b) - 1
         return _scalar(lp)
 
+    # ---- the reference's small per-cell functions, on the device sums of godot_cell_sums:
+    # s = [sum log t, sum w/t, sum iw/t, sum (w/t)^2, sum (w/t)^3, sum (iw/t)^2,
+    #      sum (w/t)(iw/t), sum (w/t)(iw/t)^2],  t = 1 + (beta-1) iw + (alpha-1) w
+    def _sums(self, alpha, beta=1.0):
+        return _np(ops.cell_sums(self._cr, alpha=float(alpha), beta=float(beta), swap=self._swap)[0])
+
+    def get_likelihood_grid(self, amax=2, bmax=2, res=0.01):
+        """logL on the grid [0, amax] x [0, bmax] of (alpha, beta) (core.py:408-425): one
+        launch, every grid point a view of the same photons."""
+        na = int(round(amax / res)) + 1
+        nb = int(round(bmax / res)) + 1
+        agrid = np.linspace(0, amax, na) - 1
+        bgrid = np.linspace(0, bmax, nb) - 1
+        cr, dev = self._cr, self._dev
+        npt = na * nb
+        grid = ops.CellRanges(cr.we, cr.lo.expand(npt).contiguous(), cr.hi.expand(npt).contiguous(),
+                              cr.S.expand(npt).contiguous(), cr.B.expand(npt).contiguous())
+        al = _to_dev(np.repeat(agrid + 1, nb), dev)
+        be = _to_dev(np.tile(bgrid + 1, na), dev)
+        s0 = _np(ops.cell_sums(grid, alpha=al, beta=be, swap=self._swap)[:, 0]).reshape(na, nb)
+        with np.errstate(invalid='ignore'):
+            rvals = s0 - self.B * (1 + bgrid)[None, :]
+            rvals -= (self.S * (1 + agrid))[:, None]
+        return agrid + 1, bgrid + 1, rvals
+
+    def log_full_likelihood(self, p):
+        """Likelihood for both source and background normalizations (core.py:427-438)."""
+        alpha, beta = float(p[0]), float(p[1])
+        return self._sums(alpha, beta)[0] - self.S * alpha - self.B * beta
+
+    def fmin_tnc_func(self, p):
+        """(-logL, [-dlogL/dalpha, -dlogL/dbeta]) as the reference hands it to fmin_tnc (core.py:440-460)."""
+        alpha, beta = float(p[0]), float(p[1])
+        if (alpha == 0) and (beta == 0):
+            return np.inf, [np.inf, np.inf]     # would call log(0)
+        s = self._sums(alpha, beta)
+        logl = s[0] - self.S * (alpha - 1) - self.B * (beta - 1)
+        return -logl, [-(s[1] - self.S), -(s[2] - self.B)]
+
+    def f1(self, alpha):
+        return self._sums(alpha)[1] - self.S
+
+    def f2(self, alpha):
+        return -self._sums(alpha)[3]
+
+    def f3(self, alpha):
+        return self._sums(alpha)[4]
+
+    def f1_profile(self, alpha):
+        """Derivative of the profile likelihood in its small-variation form (core.py:483-497)."""
+        s = self._sums(alpha)
+        T2 = s[5]
+        beta_hat = (s[2] - self.B) / T2
+        beta_hat_prime = (2 * beta_hat * s[7] - s[6]) / T2
+        s2 = self._sums(alpha, 1 + beta_hat)
+        return s2[1] + beta_hat_prime * s2[2] - self.S - beta_hat_prime * self.B
+
+    def log_profile_likelihood_approx(self, alpha):
+        """Profile over a background level assumed to vary by a few per cent (core.py:366-389)."""
+        s = self._sums(alpha)
+        beta_hat = (s[2] - self.B) / s[5]
+        return self._sums(alpha, 1 + beta_hat)[0] - alpha * self.S - (1 + beta_hat) * self.B
+
+    def nr(self, guess=1, niter=6):
+        """Newton-Raphson solution to max (core.py:509-524)."""
+        a = guess
+        for i in range(niter):
+            s = self._sums(a)
+            a = max(0, a - (s[1] - self.S) / (-s[3]))
+        return a
+
+    def halley(self, guess=1, niter=5):
+        """Halley's method solution to max (core.py:526-542)."""
+        a = guess
+        for i in range(niter):
+            s = self._sums(a)
+            f1, f2, f3 = s[1] - self.S, -s[3], 2 * s[4]
+            a = max(0, a - 2 * f1 * f2 / (2 * f2 * f2 - f1 * f3))
+        return a
+
+    def get_max_numerical(self, guess=1, beta=1, profile_background=False):
+        """The bracketing solution of the reference (core.py:693-739); the function values come
+        from the device, the one-dimensional solver is scipy's, as in the reference."""
+        if profile_background:
+            from scipy.optimize import fmin_tnc
+            rvals, nfeval, rc = fmin_tnc(self.fmin_tnc_func, [guess, beta], bounds=[[0, None], [0, None]],
+                                         disp=0, ftol=1e-3)
+            if (rc < 0) or (rc > 2):
+                print('Warning, best guess probably wrong.')
+            return rvals
+        from scipy.optimize import brentq
+
+        def f(a):
+            return self._sums(a + 1, beta)[1] - self.S
+
+        # the maximum is at zero flux if the derivative there is negative
+        if f(-1) < 0:
+            return 0
+        a0, amax = -1, guess - 1
+        for i in range(12):
+            if f(amax) < 0:
+                break
+            a0 = amax
+            amax = 2 * amax + 1
+        return brentq(f, a0, amax, xtol=1e-3) + 1
+
+    def get_beta_max_numerical(self, alpha, guess=1):
+        """core.py:825-849."""
+        from scipy.optimize import brentq
+
+        def f(b):
+            return self._sums(alpha, b + 1)[2] - self.B
+
+        if f(-1) < 0:
+            return 0
+        b0, bmax = -1, guess - 1
+        for i in range(8):
+            if f(bmax) < 0:
+                break
+            b0 = bmax
+            bmax = 2 * bmax + 1
+        return brentq(f, b0, bmax, xtol=1e-3) + 1
+
+    def get_profile_flux(self):
+        """Flux estimator after profiling over the background, from the expansion for small
+        deviations (core.py:1028-1044)."""
+        N = len(self.we)
+        w1, w2 = ops.cell_moments(self._cr.we, self._cr.lo, self._cr.hi)
+        W, W2 = _scalar(w1), _scalar(w2)
+        if self._swap:      # the kernel summed the un-swapped weights
+            W, W2 = N - W, N - 2 * W + W2
+        t1 = W2 - W
+        t2 = t1 + (N - W)
+        return ((W - self.S) * t2 + (N - self.B - W) * t1) / (W2 * t2 - t1 ** 2)
+
 
 class CellsLogLikelihood(object):
     """Batch driver: cached (ncell, 200) log-likelihood profiles, fluxes and

@@ -136,6 +136,57 @@ __global__ __launch_bounds__(256) void cell_loglike_kernel(CellArgs p, const dou
     if (lane == 0) out[cell] = v;
 }
 
+// The sums behind the reference's small per-cell functions (core.py:427-542:
+// log_full_likelihood, fmin_tnc_func, f1/f2/f3, nr, halley, f1_profile,
+// log_profile_likelihood_approx), for flux factors alpha, beta per cell, with
+// t_i = 1 + (beta - 1)(1 - w_i) + (alpha - 1) w_i:
+//   out[0] sum log t      out[1] sum w/t         out[2] sum (1-w)/t
+//   out[3] sum (w/t)^2    out[4] sum (w/t)^3     out[5] sum ((1-w)/t)^2
+//   out[6] sum (w/t)((1-w)/t)                    out[7] sum (w/t)((1-w)/t)^2
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_sums_kernel(CellArgs p, const double *alpha, double alpha0,
+                                                        const double *beta, double beta0, double *out)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    p.S = alpha ? alpha : out;   // S, B are not used here; keeps cell_setup's loads in bounds
+    p.B = nullptr;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, p.swap != 0);
+    const double a = (alpha ? alpha[cell] : alpha0) - 1.0;
+    const double b = (beta ? beta[cell] : beta0) - 1.0;
+    const double ab = a - b, b1 = 1.0 + b;
+    double acc[7];
+    cd.template sums<7>([=](double w, double (&s)[7]) {
+        const double t = fma(w, ab, b1);
+        const double x = w / t, y = (1.0 - w) / t;
+        s[0] += x;
+        s[1] += y;
+        s[2] = fma(x, x, s[2]);
+        s[3] = fma(x * x, x, s[3]);
+        s[4] = fma(y, y, s[4]);
+        s[5] = fma(x, y, s[5]);
+        s[6] = fma(x * y, y, s[6]);
+    }, acc);
+    // a negative t makes the reference's sum of logarithms NaN; two of them would hide
+    // each other in the product, so they are counted
+    double ls, nneg;
+    cd.logsum([=](double w, double &t, double &g) {
+        t = fma(w, ab, b1);
+        g = t < 0.0 ? 1.0 : 0.0;
+    }, ls, nneg);
+    if (nneg > 0.0) ls = qnan();
+    if (lane == 0) {
+        double *o = out + cell * 8;
+        o[0] = bad ? qnan() : ls;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[1 + k] = bad ? qnan() : acc[k];
+    }
+}
+
 template <int T, int R>
 __global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *wsum, double *w2sum)
 {
@@ -585,6 +636,21 @@ extern "C" int godot_cell_loglike(const double *we, int64_t nph, const int64_t *
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     DISPATCH_TEAM(pick_team(nph, ncell), cell_loglike_kernel, 0, p, alpha, logl);
     GODOT_LAUNCH_CHECK("godot_cell_loglike");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_sums(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, int64_t ncell,
+                               const double *alpha, double alpha0, const double *beta, double beta0, int swap,
+                               double *sums, godot_stream_t stream)
+{
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_sums");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(sums, GODOT_E_INVALID, "godot_cell_sums: null output");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, swap};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_sums_kernel, 0, p, alpha, alpha0, beta, beta0, sums);
+    GODOT_LAUNCH_CHECK("godot_cell_sums");
     return GODOT_OK;
 }
 

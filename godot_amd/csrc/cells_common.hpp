@@ -569,11 +569,14 @@ __device__ double fit_alpha(const CD &cd, double S, double guess, double beta, i
 template <class CD>
 __device__ double loglike(const CD &cd, double S, double alpha)
 {
-    double ls, unused;
+    // a negative factor makes the reference's sum of logarithms NaN (core.py:361-364);
+    // the product of two of them would not show it, so they are counted
+    double ls, nneg;
     cd.logsum([=](double w, double &t, double &g) {
         t = fma(w, alpha, 1.0 - w);
-        g = 0.0;
-    }, ls, unused);
+        g = t < 0.0 ? 1.0 : 0.0;
+    }, ls, nneg);
+    if (nneg > 0.0) ls = qnan();
     return ls - S * alpha;
 }
 

@@ -113,6 +113,20 @@ def cell_loglike(cr, alpha, swap=False):
     return out
 
 
+def cell_sums(cr, alpha=1.0, beta=1.0, swap=False):
+    """(ncell, 8) sums over each cell's photons at flux factors alpha, beta, with
+    t = 1 + (beta-1)(1-w) + (alpha-1)w: sum log t, sum w/t, sum (1-w)/t, sum (w/t)^2,
+    sum (w/t)^3, sum ((1-w)/t)^2, sum (w/t)((1-w)/t), sum (w/t)((1-w)/t)^2."""
+    n, dev = cr.ncell, cr.device
+    at, a0 = _per_cell(alpha, n, dev, 'alpha')
+    bt, b0 = _per_cell(beta, n, dev, 'beta')
+    out = torch.empty((n, 8), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_sums', *cr._head(), n, _p(at), a0, _p(bt), b0, int(bool(swap)), _p(out),
+                  _stream(dev))
+    return out
+
+
 def cell_logpdf(cr, aopt=None, dlogl=20., npt=100, include_zero=False, swap=False):
     n, dev = cr.ncell, cr.device
     if aopt is not None:

@@ -230,6 +230,21 @@ int godot_bin_photons(const double *ti, int64_t nph, double start0,
                       int64_t *lo, int64_t *hi, int64_t *counts,
                       godot_stream_t stream);
 
+/* The per-photon sums behind the reference's small per-cell functions:
+ * log_full_likelihood (core.py:427-438), fmin_tnc_func (440-460), f1/f2/f3
+ * (479-507), nr (509-524), halley (526-542), f1_profile (483-497) and
+ * log_profile_likelihood_approx (366-389).  With flux factors alpha, beta per
+ * cell (arrays, or NULL and the scalar) and t_i = 1 + (beta-1)(1-w_i) +
+ * (alpha-1) w_i, sums[cell][0..7] =
+ *   sum log t, sum w/t, sum (1-w)/t, sum (w/t)^2, sum (w/t)^3,
+ *   sum ((1-w)/t)^2, sum (w/t)((1-w)/t), sum (w/t)((1-w)/t)^2.
+ * swap != 0: on the complemented weights.                                      */
+int godot_cell_sums(const double *we, int64_t nph,
+                    const int64_t *lo, const int64_t *hi, int64_t ncell,
+                    const double *alpha, double alpha0,
+                    const double *beta, double beta0, int swap,
+                    double *sums, godot_stream_t stream);
+
 /* Per-cell moments sum(w), sum(w^2) (core.py:2178-2183).                      */
 int godot_cell_moments(const double *we, int64_t nph,
         const int64_t *lo, const int64_t *hi,

@@ -429,3 +429,57 @@ def test_profile_background_lightcurve_close_to_reference(golden):
     assert np.abs(lc[m, 5] - ref[m, 5]).max() < 0.05 + 1e-3 * np.abs(ref[m, 5]).max()
     assert np.abs(lc[m, 2] - ref[m, 2]).max() < 0.05
     assert np.array_equal(lc[:, 0], ref[:, 0]) and np.allclose(lc[:, 1], ref[:, 1], rtol=1e-12)
+
+
+def test_small_per_cell_functions_match_reference(golden):
+    """log_full_likelihood, fmin_tnc_func, f1/f2/f3, f1_profile,
+    log_profile_likelihood_approx, nr, halley, the bracketing maxima and
+    get_profile_flux of the single-cell API, evaluated through godot_cell_sums."""
+    from godot_amd import core
+    g = golden('cell_aux.npz')
+    alphas, points = g['alphas'], g['points']
+
+    def close(got, ref, what, rtol=RTOL):
+        got, ref = np.asarray(got, dtype=float), np.asarray(ref, dtype=float)
+        scale = np.maximum(1.0, np.abs(ref))
+        with np.errstate(invalid='ignore'):
+            ok = (np.abs(got - ref) <= rtol * scale) | (np.isnan(got) & np.isnan(ref))
+        assert ok.all(), (what, got, ref)
+
+    for ic in range(int(g['ncase'])):
+        for swap in (False, True):
+            tag = 'c%d%s_' % (ic, 's' if swap else '')
+            tstart, tstop, exp, SonB = g[tag + 'cell']
+            we = g[tag + 'we']
+            cell = core.Cell(tstart, tstop, exp, np.zeros(len(we)), we, SonB)
+            cl = core.CellLogLikelihood(cell, swap=swap)
+            n = max(1, len(we))
+            close([cl.log_full_likelihood(list(p)) for p in points], g[tag + 'full'], tag + 'full', RTOL * n)
+            tn = [cl.fmin_tnc_func(list(p)) for p in points]
+            close([[t[0], t[1][0], t[1][1]] for t in tn], g[tag + 'tnc'], tag + 'tnc', RTOL * n)
+            close([[cl.f1(a), cl.f2(a), cl.f3(a)] for a in alphas], g[tag + 'f123'], tag + 'f123', RTOL * n)
+            close([cl.f1_profile(a) for a in alphas], g[tag + 'f1_profile'], tag + 'f1_profile', 1e-8 * n)
+            close([cl.log_profile_likelihood_approx(a) for a in alphas], g[tag + 'lpl_approx'], tag + 'lpl',
+                  1e-8 * n)
+            close([cl.nr(), cl.nr(guess=2.5, niter=3)], g[tag + 'nr'], tag + 'nr')
+            close([cl.halley(), cl.halley(guess=0.4, niter=2)], g[tag + 'halley'], tag + 'halley')
+            # brentq stops within xtol = 1e-3: same function to rounding, same iterates
+            close([cl.get_max_numerical(), cl.get_max_numerical(guess=3, beta=1.2)], g[tag + 'max_num'],
+                  tag + 'max_num', 1e-6)
+            close([cl.get_beta_max_numerical(a) for a in (0.5, 1.0, 2.0)], g[tag + 'beta_num'], tag + 'beta_num',
+                  1e-6)
+            close(cl.get_profile_flux(), g[tag + 'profile_flux'], tag + 'profile_flux', 1e-9 * n)
+            if (tag + 'grid') in g:
+                ag, bg, rv = cl.get_likelihood_grid(amax=3, bmax=2, res=0.25)
+                assert np.array_equal(ag, g[tag + 'grid_a']) and np.array_equal(bg, g[tag + 'grid_b'])
+                ref = g[tag + 'grid']
+                assert rv.shape == ref.shape
+                # (alpha, beta) = (0, 0) is log(0) per photon: -inf here, NaN or -inf in the reference
+                # (its t = 1 - w - (1 - w) rounds to +-1e-17); everywhere else the grids agree
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(rv), fin) and not fin[0, 0]
+                close(rv[fin], ref[fin], tag + 'grid', RTOL * n)
+            # fmin_tnc (ftol 1e-3): an optimiser on nearly the same numbers; its own tolerance applies
+            mp = cl.get_max_numerical(profile_background=True)
+            ref = g[tag + 'max_num_profile']
+            assert cl.log_full_likelihood(list(mp)) >= cl.log_full_likelihood(list(ref)) - 2e-3
