@@ -468,6 +468,17 @@ class CellLogLikelihood(object):
         logl = s[0] - self.S * (alpha - 1) - self.B * (beta - 1)
         return -logl, [-(s[1] - self.S), -(s[2] - self.B)]
 
+    def fmin_fsolve(self, p):
+        """The gradient as the reference hands it to fsolve (core.py:462-474); it prints its argument."""
+        s = self._sums(float(p[0]), float(p[1]))
+        grad_alpha, grad_beta = s[1] - self.S, s[2] - self.B
+        print(p, grad_alpha, grad_beta)
+        return [-grad_alpha, -grad_beta]
+
+    def _get_logpdf_profile(self, aopt=None, dlogl=20, npt=100, include_zero=False):
+        return self.get_logpdf(aopt=aopt, dlogl=dlogl, npt=npt, include_zero=include_zero,
+                               profile_background=True)
+
     def f1(self, alpha):
         return self._sums(alpha)[1] - self.S
 
@@ -611,6 +622,18 @@ class CellsLogLikelihood(object):
 
     def __len__(self):
         return len(self.cells)
+
+    def sanity_check(self):
+        """Report cells with a suspiciously narrow support or a profile that does not peak at
+        its maximum (reference core.py:1100-1106)."""
+        dx = self._dom[:, -1] - self._dom[:, 0]
+        bad_x = _np(torch.nonzero(dx.abs() < 1e-3).ravel())
+        print('Indices with suspiciously narrow support ranges: ', bad_x)
+        ymax = self._cod.max(dim=1).values
+        bad_y = _np(torch.nonzero(ymax.abs() > 0.2).ravel())
+        print('Indices where there is a substantial disagreement in the optimized value of the log '
+              'likelihood and the codomain: ', bad_y)
+        return bad_x, bad_y
 
     def get_flux_all(self, conf=[0.05, 0.95]):
         """(aopt, ts, xlo, xhi) device tensors for every cell."""
@@ -822,6 +845,12 @@ class CellsLogLikelihoodOld(object):
         self.tmids = 0.5 * (batch.starts + batch.stops)
         self._cr = batch.ranges()
 
+    def log_likelihood(self, alpha):
+        """Alpha is a vector with one entry per cell (reference core.py:2415-2423)."""
+        al = _to_dev(alpha, self._cr.device)
+        # per cell: sum log(alpha w + 1 - w) - exp alpha (a cell's S is its exposure)
+        return float(ops.cell_loglike(self._cr, al).sum().cpu())
+
 
 # ---------------------------------------------------------------------------
 # Data: the array tail of the reference's Data class (core.py:1792-1843, 1958-2206)
@@ -888,6 +917,36 @@ class Data(object):
         return ops.exposure_at(self.TSTART, self.TSTOP, self.exposure, self.LIVETIME,
                                self.S / self.E, self.B / self.E, self._exposure_table, t,
                                cumulative=cumulative, deadtime_too=deadtime_too)
+
+    def get_deadtime(self, times):
+        """Cumulative dead time at the given times (reference core.py:1845-1847)."""
+        return self.get_exposure(times, deadtime_too=True)[-1]
+
+    def zero_weight(self, tstart, tstop):
+        """Remove the exposure rows that lie inside [tstart, tstop] and the photons that fall in
+        them; totals S, B, E follow (reference core.py:1593-1618)."""
+        tstart = float(infer_met(tstart))
+        tstop = float(infer_met(tstop))
+        keep = ~((self.TSTART >= tstart) & (self.TSTOP <= tstop))
+        row = ops.search_sorted(self.TSTOP, self.ti)
+        if bool((row >= keep.numel()).any().cpu()):
+            raise IndexError('a photon lies after the last exposure row')
+        event_keep = keep[row]
+        self.exposure = self.exposure[keep].contiguous()
+        self.TSTART = self.TSTART[keep].contiguous()
+        self.TSTOP = self.TSTOP[keep].contiguous()
+        self.LIVETIME = self.LIVETIME[keep].contiguous()
+        self.ti = self.ti[event_keep].contiguous()
+        self.we = self.we[event_keep].contiguous()
+        self.E = float(np.cumsum(_np(self.exposure))[-1])      # the reference's E is cumsum(exposure)[-1]
+        self.S = float(np.sum(_np(self.we)))
+        self.B = self.we.numel() - self.S
+        self._t0 = float(self.TSTART[0].cpu())
+        self._t1 = float(self.TSTOP[-1].cpu())
+        self._exposure_table = None
+        self._scaled_tables = {}
+        self._scaled_key = None
+        self._ft2_host = None
 
     def _ft2(self):
         if self._ft2_host is None:

@@ -483,3 +483,29 @@ def test_small_per_cell_functions_match_reference(golden):
             mp = cl.get_max_numerical(profile_background=True)
             ref = g[tag + 'max_num_profile']
             assert cl.log_full_likelihood(list(mp)) >= cl.log_full_likelihood(list(ref)) - 2e-3
+
+
+def test_flat_layout_likelihood_and_zero_weight_match_reference(golden):
+    """CellsLogLikelihoodOld.log_likelihood (one alpha per cell) and Data.zero_weight
+    followed by binning."""
+    from godot_amd import core
+    g = golden('cell_aux.npz')
+    dev = _dev()
+    data = core.Data(g['in_ti'], g['in_we'], g['in_TSTART'], g['in_TSTOP'], g['in_LIVETIME'], g['in_exposure'],
+                     device=dev)
+    cells = data.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+    n = int(g['old_ncell'])
+    old = core.CellsLogLikelihoodOld([cells[i] for i in range(n)], device=dev)
+    ll = old.log_likelihood(g['old_alpha'])
+    assert abs(ll - float(g['old_ll'])) <= RTOL * abs(float(g['old_ll']))
+    a, b = g['zw_range']
+    data.zero_weight(a, b)
+    S, B, E, nph, nrow = g['zw_totals']
+    assert data.ti.numel() == int(nph) and data.TSTART.numel() == int(nrow)
+    assert abs(data.S - S) <= 1e-12 * S and abs(data.B - B) <= 1e-12 * B and data.E == E
+    zc = data.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+    assert np.array_equal(zc.starts.cpu().numpy(), g['zw_starts'])
+    assert np.array_equal((zc.hi - zc.lo).cpu().numpy(), g['zw_counts'])
+    assert np.allclose(zc.sexp.cpu().numpy(), g['zw_exp'], rtol=1e-12, atol=0)
+    dt = data.get_deadtime(torch.tensor([g['zw_starts'][0], g['zw_starts'][-1]], dtype=torch.float64, device=dev))
+    assert float(dt[1]) > float(dt[0]) >= 0

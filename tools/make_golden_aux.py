@@ -57,6 +57,26 @@ def main(outdir):
                     with np.errstate(all='ignore'):
                         ag, bg, rv = cl.get_likelihood_grid(amax=3, bmax=2, res=0.25)
                     out[tag + 'grid_a'], out[tag + 'grid_b'], out[tag + 'grid'] = ag, bg, rv
+    # many cells at once, the flat-layout class
+    with mg.quiet():
+        old = core.CellsLogLikelihoodOld(cells[:25])
+        avec = np.random.default_rng(2).uniform(0.2, 3.0, 25)
+        out['old_alpha'] = avec
+        out['old_ll'] = np.array(old.log_likelihood(avec))
+    out['old_ncell'] = np.array(25)
+    # zero_weight: drop three days of exposure and their photons, then bin
+    d2 = mg.make_data(core, d)
+    d2.cexposure = np.cumsum(d2.exposure)
+    t0 = d['TSTART'][0]
+    with mg.quiet():
+        d2.zero_weight(t0 + 3.2 * 86400, t0 + 6.1 * 86400)
+        zc = d2.get_cells(tcell=86400., use_barycenter=False)
+    out['zw_range'] = np.array([t0 + 3.2 * 86400, t0 + 6.1 * 86400])
+    out['zw_totals'] = np.array([d2.S, d2.B, d2.E, len(d2.ti), len(d2.TSTART)])
+    out['zw_starts'] = np.array([c.tstart for c in zc])
+    out['zw_exp'] = np.array([c.exp for c in zc])
+    out['zw_counts'] = np.array([len(c.we) for c in zc], dtype=np.int64)
+    out.update(mg.inputs_of(d))
     out['ncase'] = np.array(len(pick))
     out['alphas'] = np.array(ALPHAS)
     out['points'] = np.array(POINTS)
