@@ -288,7 +288,8 @@ __global__ __launch_bounds__(SEQ_THREADS) void exposure_cumsum_kernel(ExposureLo
 //   4. one workgroup per series walks the chunks with the exact s: a regular
 //      chunk is accepted if s really lies in binade k and the sum stays below
 //      2^(k+1) (x >= 0: then every partial sum does) and costs one integer
-//      addition; any other chunk is added row by row, as numpy does;
+//      addition -- runs of sixteen such chunks are composed beforehand and
+//      taken in one step; any other chunk is added row by row, as numpy does;
 //   5. per accepted chunk: the scan inside the chunk from its exact start.
 // A binade is crossed some forty times in a ten-year table, so all but a few
 // dozen chunks per series go the parallel way.
@@ -297,6 +298,7 @@ constexpr int CS_CHUNK = 2048;
 constexpr int CS_THREADS = 256;
 constexpr int CS_RPT = CS_CHUNK / CS_THREADS;
 constexpr int CS_INFO_TILE = 2048;          // chunk records staged in LDS per trip of the walk
+constexpr int CS_GROUP = 16;                // chunks composed into one step of the walk
 constexpr int CS_K_ANY = INT32_MIN;         // all-zero chunk: leaves any s unchanged
 constexpr int64_t CS_2P53 = (int64_t)1 << 53;
 
@@ -484,6 +486,11 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
     __shared__ int32_t s_by[CS_INFO_TILE];
     __shared__ double s_x[CS_CHUNK];
     __shared__ int64_t s_chunk;
+    // runs of CS_GROUP chunks that share a binade, composed into one adder each: thread 0
+    // steps over a whole run when the sum stays inside the binade to its end
+    __shared__ ChunkInfo s_group[CS_INFO_TILE / CS_GROUP];
+    __shared__ int64_t s_gbits[CS_INFO_TILE / CS_GROUP];
+    __shared__ int32_t s_gtaken[CS_INFO_TILE / CS_GROUP];
     constexpr int64_t MANT = ((int64_t)1 << 52) - 1;
     const int tid = threadIdx.x, col = blockIdx.x;
     double *cumd = (double *)cum;
@@ -492,12 +499,55 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
         const int64_t tile1 = tile0 + CS_INFO_TILE < nchunk ? tile0 + CS_INFO_TILE : nchunk;
         for (int64_t c = tile0 + tid; c < tile1; c += CS_THREADS) s_info[c - tile0] = info[c * 4 + col];
         __syncthreads();
+        const int tlen = (int)(tile1 - tile0);
+        for (int g = tid; g * CS_GROUP < tlen; g += CS_THREADS) {
+            const int q1 = (g + 1) * CS_GROUP < tlen ? (g + 1) * CS_GROUP : tlen;
+            Adder f{0, 0};
+            int k = CS_K_ANY;
+            bool ok = true;
+            for (int q = g * CS_GROUP; q < q1; ++q) {
+                const ChunkInfo in = s_info[q];
+                ok = ok && in.regular;
+                if (in.k != CS_K_ANY) {
+                    ok = ok && (k == CS_K_ANY || k == in.k);
+                    k = in.k;
+                    f = adder_then(f, Adder{in.even, in.odd});
+                }
+            }
+            ok = ok && f.even >= 0 && f.odd >= 0 && f.even < CS_2P53 && f.odd < CS_2P53;
+            s_group[g] = ChunkInfo{f.even, f.odd, k, ok ? 1 : 0};
+            s_gtaken[g] = 0;
+        }
+        __syncthreads();
         int64_t chunk = tile0;
         while (true) {
             if (tid == 0) {
                 // over the chunks that go the parallel way
                 int64_t bits = __double_as_longlong(s);
                 while (chunk < tile1) {
+                    const int ci = (int)(chunk - tile0);
+                    if ((ci % CS_GROUP) == 0 && s_group[ci / CS_GROUP].regular) {
+                        // the whole run at once, if the sum is in its binade and stays there
+                        const ChunkInfo gi = s_group[ci / CS_GROUP];
+                        int64_t nb = bits;
+                        bool ok = true;
+                        if (gi.k != CS_K_ANY) {
+                            const int64_t ex = bits >> 52;
+                            ok = ex == (int64_t)gi.k + 1023 && ex > 0 && ex < 2047;
+                            if (ok) {
+                                const int64_t S2 = adder_apply((bits & MANT) | (MANT + 1), Adder{gi.even, gi.odd});
+                                ok = S2 < CS_2P53;
+                                nb = (ex << 52) | (S2 & MANT);
+                            }
+                        }
+                        if (ok) {
+                            s_gbits[ci / CS_GROUP] = bits;
+                            s_gtaken[ci / CS_GROUP] = 1;
+                            bits = nb;
+                            chunk += (tlen - ci) < CS_GROUP ? (tlen - ci) : CS_GROUP;
+                            continue;
+                        }
+                    }
                     const ChunkInfo in = s_info[chunk - tile0];
                     if (!in.regular) break;
                     if (in.k != CS_K_ANY) {
@@ -553,6 +603,24 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
             for (int r = tid; r < m; r += CS_THREADS) cumd[(base + r) * 4 + col] = s_x[r];
             ++chunk;
             __syncthreads();
+        }
+        __syncthreads();
+        // the chunks inside the runs taken whole: their starts follow from the run's start
+        for (int ci = tid; ci < tlen; ci += CS_THREADS) {
+            const int g = ci / CS_GROUP;
+            if (!s_gtaken[g]) continue;
+            int64_t bits = s_gbits[g];
+            if (s_group[g].k != CS_K_ANY) {
+                const int64_t ex = bits >> 52;
+                int64_t S = (bits & MANT) | (MANT + 1);
+                for (int q = g * CS_GROUP; q < ci; ++q) {
+                    const ChunkInfo in = s_info[q];
+                    if (in.k != CS_K_ANY) S = adder_apply(S, Adder{in.even, in.odd});
+                }
+                bits = (ex << 52) | (S & MANT);
+            }
+            s_entry[ci] = __longlong_as_double(bits);
+            s_by[ci] = 0;
         }
         __syncthreads();
         for (int64_t c = tile0 + tid; c < tile1; c += CS_THREADS) {
