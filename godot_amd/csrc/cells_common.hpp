@@ -769,13 +769,12 @@ inline int pick_team(int64_t nph, int64_t ncell)
 {
     double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
     double need = mean + 4.0 * sqrt(mean) + 8.0;
-    if (need <= 32) return 0;     // 4 x 8
-    if (need <= 64) return 1;     // 8 x 8
-    if (need <= 128) return 2;    // 8 x 16
-    if (need <= 256) return 3;    // 8 x 32
-    if (need <= 512) return 4;    // 16 x 32
-    if (need <= 1024) return 5;   // 32 x 32
-    return 6;                     // 64 x 32, larger cells stream from L2
+    // T x R register slots, in steps of a quarter to a half: a shape twice too large
+    // spends half of every pass on padding
+    static const int slots[] = {32, 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536};
+    for (int k = 0; k < (int)(sizeof(slots) / sizeof(slots[0])); ++k)
+        if (need <= slots[k]) return k;
+    return 15;                    // 64 x 32, larger cells stream from L2
 }
 
 inline int check_cells(const void *we, int64_t nph, const void *lo, const void *hi, int64_t ncell,
@@ -800,10 +799,19 @@ inline int check_cells(const void *we, int64_t nph, const void *lo, const void *
         switch (CFG_) {                                                                     \
         case 0: DISPATCH_ONE(4, 8, KERNEL, __VA_ARGS__)                                     \
         case 1: DISPATCH_ONE(8, 8, KERNEL, __VA_ARGS__)                                     \
-        case 2: DISPATCH_ONE(8, 16, KERNEL, __VA_ARGS__)                                    \
-        case 3: DISPATCH_ONE(8, 32, KERNEL, __VA_ARGS__)                                    \
-        case 4: DISPATCH_ONE(16, 32, KERNEL, __VA_ARGS__)                                   \
-        case 5: DISPATCH_ONE(32, 32, KERNEL, __VA_ARGS__)                                   \
+        case 2: DISPATCH_ONE(8, 12, KERNEL, __VA_ARGS__)                                    \
+        case 3: DISPATCH_ONE(8, 16, KERNEL, __VA_ARGS__)                                    \
+        case 4: DISPATCH_ONE(8, 20, KERNEL, __VA_ARGS__)                                    \
+        case 5: DISPATCH_ONE(8, 24, KERNEL, __VA_ARGS__)                                    \
+        case 6: DISPATCH_ONE(8, 32, KERNEL, __VA_ARGS__)                                    \
+        case 7: DISPATCH_ONE(16, 20, KERNEL, __VA_ARGS__)                                   \
+        case 8: DISPATCH_ONE(16, 24, KERNEL, __VA_ARGS__)                                   \
+        case 9: DISPATCH_ONE(16, 32, KERNEL, __VA_ARGS__)                                   \
+        case 10: DISPATCH_ONE(32, 20, KERNEL, __VA_ARGS__)                                  \
+        case 11: DISPATCH_ONE(32, 24, KERNEL, __VA_ARGS__)                                  \
+        case 12: DISPATCH_ONE(32, 32, KERNEL, __VA_ARGS__)                                  \
+        case 13: DISPATCH_ONE(64, 20, KERNEL, __VA_ARGS__)                                  \
+        case 14: DISPATCH_ONE(64, 24, KERNEL, __VA_ARGS__)                                  \
         default: DISPATCH_ONE(64, 32, KERNEL, __VA_ARGS__)                                  \
         }                                                                                   \
     } while (0)

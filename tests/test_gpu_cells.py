@@ -509,3 +509,52 @@ def test_flat_layout_likelihood_and_zero_weight_match_reference(golden):
     assert np.allclose(zc.sexp.cpu().numpy(), g['zw_exp'], rtol=1e-12, atol=0)
     dt = data.get_deadtime(torch.tensor([g['zw_starts'][0], g['zw_starts'][-1]], dtype=torch.float64, device=dev))
     assert float(dt[1]) > float(dt[0]) >= 0
+
+
+@pytest.mark.parametrize('mean', [40, 100, 130, 228, 290, 450, 600, 950, 1200])
+def test_dense_team_shapes(mean):
+    """One occupancy per register-slot shape of the team kernels between the
+    power-of-two ones (8x12 ... 64x24): fit, TS, likelihood, moments and the
+    profile grid against the oracle."""
+    from godot_amd import ops
+    dev = _dev()
+    ncell = 260
+    rng = np.random.default_rng(mean)
+    cnt = rng.poisson(mean, ncell).astype(np.int64)
+    cnt[:2] = 0
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = np.maximum(cnt * 0.17 * rng.uniform(0.3, 3, ncell), 0.05)
+    B = S * 5
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev))
+    alpha, ts, flags = ops.cell_fit(cr, beta=1.3)
+    a13, t13 = alpha.cpu().numpy(), ts.cpu().numpy()
+    alpha, ts, flags = ops.cell_fit(cr)
+    ll = ops.cell_loglike(cr, alpha).cpu().numpy()
+    w1, w2 = ops.cell_moments(cr.we, cr.lo, cr.hi)
+    dom, cod, lfl = ops.cell_logpdf(cr, dlogl=30, npt=200)
+    a, t, dom, cod = alpha.cpu().numpy(), ts.cpu().numpy(), dom.cpu().numpy(), cod.cpu().numpy()
+    assert not (flags.cpu().numpy() & 0x10).any() and not (lfl.cpu().numpy() & 0x10).any()
+    pick = np.concatenate([[0, 1], rng.choice(np.arange(2, ncell), 40, replace=False)])
+    with np.errstate(all='ignore'):
+        for c in pick:
+            w = we[off[c]:off[c + 1]]
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            ar = cl.get_max()
+            assert abs(a[c] - ar) <= RTOL * max(1, abs(ar)), (c, cnt[c])
+            assert abs(t[c] - cl.get_ts(ar)) <= RTOL * max(sc, abs(t[c])), (c, cnt[c])
+            ab = cl.get_max(beta=1.3)
+            assert abs(a13[c] - ab) <= RTOL * max(1, abs(ab)), (c, cnt[c])
+            assert abs(ll[c] - cl.log_likelihood(ar)) <= RTOL * max(sc, abs(ll[c])), (c, cnt[c])
+            assert abs(float(w1[c]) - w.sum()) <= 1e-12 * max(1.0, w.sum())
+            assert abs(float(w2[c]) - (w * w).sum()) <= 1e-12 * max(1.0, w.sum())
+        for c in pick[:8]:
+            w = we[off[c]:off[c + 1]]
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            d, v = orc.CellLike(w, S[c], S[c] / B[c]).get_logpdf(dlogl=30, npt=200)
+            if np.isnan(d).any() or np.isnan(v).any():
+                continue
+            assert np.abs(dom[c] - d).max() <= RTOL * max(1.0, np.abs(d).max()), (c, cnt[c])
+            assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), (c, cnt[c])
