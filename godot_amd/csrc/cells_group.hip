@@ -909,7 +909,9 @@ bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R)
     const double need = mean + 2.0 * sqrt(mean);
     if (need <= 9.0) { L = 1; R = 8; }
     else if (need <= 17.0) { L = 1; R = 16; }
+    else if (need <= 25.0) { L = 2; R = 12; }
     else if (need <= 33.0) { L = 2; R = 16; }
+    else if (need <= 49.0) { L = 4; R = 12; }
     else if (need <= 66.0) { L = 4; R = 16; }
     else return false;
     return true;
@@ -953,8 +955,10 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     }
     GK_LAUNCH_TWO(1, 8)
     GK_LAUNCH_TWO(1, 16)
-    GK_LAUNCH_TWO(2, 16)
+    GK_LAUNCH_TWO(2, 12)
+    GK_LAUNCH_INPLACE(2, 12)
     GK_LAUNCH_INPLACE(2, 16)
+    GK_LAUNCH_INPLACE(4, 12)
     GK_LAUNCH_INPLACE(4, 16)
 #undef GK_LAUNCH_INPLACE
 #undef GK_LAUNCH_TWO
@@ -973,7 +977,9 @@ void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int6
                            npt, include_zero, dom, cod, flags);
     GP_LAUNCH(1, 8)
     GP_LAUNCH(1, 16)
+    GP_LAUNCH(2, 12)
     GP_LAUNCH(2, 16)
+    GP_LAUNCH(4, 12)
     GP_LAUNCH(4, 16)
 #undef GP_LAUNCH
 }

@@ -185,7 +185,8 @@ def test_fit_matches_oracle_on_random_cells(nph, ncell):
 
 
 @pytest.mark.parametrize('mean,variant', [
-    (4, 'plain'), (4, 'guess'), (12.5, 'plain'), (12.5, 'beta'), (12.5, 'scattered'),
+    (4, 'plain'), (4, 'guess'), (9, 'plain'), (12.5, 'plain'), (12.5, 'beta'), (12.5, 'scattered'), (17, 'plain'),
+    (30, 'plain'), (30, 'beta'), (30, 'guess'),
     (22, 'plain'), (22, 'guess'), (22, 'beta'), (22, 'scattered'), (22, 'swap'), (40, 'plain'), (40, 'beta'),
     (22, 'outliers')])
 def test_fit_sparse_cell_kernels(mean, variant):
@@ -249,7 +250,8 @@ def test_fit_sparse_cell_kernels(mean, variant):
         assert (depth > 0).any()        # the restart path was exercised
 
 
-@pytest.mark.parametrize('mean,variant', [(4, 'plain'), (12.5, 'plain'), (22, 'plain'), (22, 'swap'),
+@pytest.mark.parametrize('mean,variant', [(4, 'plain'), (9, 'plain'), (12.5, 'plain'), (17, 'plain'), (30, 'plain'),
+                                          (22, 'plain'), (22, 'swap'),
                                           (22, 'outliers'), (22, 'given'), (40, 'plain'), (22, 'npt300')])
 def test_logpdf_sparse_cell_kernels(mean, variant):
     """Profile grids of the sparse-cell kernel in every shape against the
