@@ -60,7 +60,18 @@ def _to_dev(x, dev, dtype=F64):
 
 
 def _np(x):
-    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    """Host copy as a numpy array.  Large device tensors go through page-locked memory
+    (several times the rate of a copy into pageable memory); the array owns that buffer."""
+    if not isinstance(x, torch.Tensor):
+        return np.asarray(x)
+    x = x.detach()
+    if x.is_cuda and x.numel() * x.element_size() >= (1 << 20):
+        x = x.contiguous()
+        h = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+        h.copy_(x, non_blocking=True)
+        torch.cuda.current_stream(x.device).synchronize()
+        return h.numpy()
+    return x.cpu().numpy()
 
 
 # ---------------------------------------------------------------------------
@@ -783,7 +794,7 @@ class CellsLogLikelihood(object):
                                    self._cr.S, tsmin)
         out = np.empty([len(self.cells), 6])
         out[:, 1:] = _np(rows)
-        tmid = 0.5 * (_np(self.cells.starts) + _np(self.cells.stops))
+        tmid = _np(0.5 * (self.cells.starts + self.cells.stops))
         out[:, 0] = met2mjd(tmid)
         return out
 
