@@ -512,7 +512,9 @@ __global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *do
             ibest = oi;
         }
     }
-    __syncthreads();
+    // the slice belongs to this wavefront alone and LDS serves a wavefront's accesses in
+    // order: only the compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // cumulative trapezoid: cdf[0] = 0, cdf[i+1] = cdf[i] + (x[i+1]-x[i]) (y[i+1]+y[i]) / 2
     double carry = 0.0;
     const int nseg = npt - 1;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *do
             if (i < nseg) s_cdf[i + 1] = incl;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (!active) return;
     // normalise, locate the quantiles: searchsorted(cdf, conf) (side='left')
     const double inv = 1. / carry;
