@@ -96,6 +96,30 @@ def test_c2_fit_is_the_maximum_and_ts_is_the_likelihood_ratio(c2):
             assert abs(t[c] - tr) <= RTOL * max(sc, abs(tr)), (c, t[c], tr)
 
 
+def test_c2_every_cell_matches_the_oracle(c2):
+    """All 4.4e5 cells of the headline workload against the oracle's get_max + get_ts
+    (about 20 s of CPU), not a sample."""
+    from godot_amd import ops
+    s, data, cells = c2
+    cr = cells.ranges()
+    alpha, ts, flags = ops.cell_fit(cr)
+    a, t, fl = _n(alpha), _n(ts), _n(flags)
+    we, lo, hi, S, B = _n(cr.we), _n(cr.lo), _n(cr.hi), _n(cr.S), _n(cr.B)
+    ref_a = np.empty(len(a))
+    ref_t = np.empty(len(a))
+    scale = np.empty(len(a))
+    with np.errstate(all='ignore'):
+        for c in range(len(a)):
+            w = we[lo[c]:hi[c]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            ref_a[c] = cl.get_max()
+            ref_t[c] = cl.get_ts(ref_a[c])
+            scale[c] = max(1.0, -np.log1p(-w).sum())
+    assert (np.abs(a - ref_a) <= RTOL * np.maximum(1.0, np.abs(ref_a))).all()
+    assert (np.abs(t - ref_t) <= RTOL * np.maximum(scale, np.abs(ref_t))).all()
+    assert np.array_equal((fl & 1) != 0, ref_a == 0)
+
+
 def test_c2_fit_does_not_depend_on_how_the_job_is_split(c2):
     """Cell ranges fitted on their own (what a rank does, on its own slice of the
     photons) reproduce the whole job: no cell sees its neighbours.  The kernel
