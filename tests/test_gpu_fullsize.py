@@ -196,3 +196,25 @@ def test_c4_trig_sums_add_and_match_the_oracle_at_spot_frequencies():
     s2, q2 = ops.z2m_sums(td[cut:].contiguous(), wd[cut:].contiguous(), f0, df, n, m=2, j0=j0)
     zz, _ = ops.z2m_finish(s1 + s2, q1 + q2)
     assert np.abs(_n(zz) - zn[j0:j0 + n]).max() <= 1e-10 * max(1.0, zn[j0:j0 + n].max())
+
+
+def test_c3_power_spectrum_matches_numpy_transforms():
+    """C3: twelve years of 100-s bins (3 786 912 of them, padded to l = 2^25): the
+    device spectra against the oracle's five numpy transforms of the same series."""
+    from godot_amd import core, synth
+    s = synth.synth(2_000_000, years=12.0, seed=13)
+    data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=DEV)
+    ts = data.get_cells(tcell=100.0, time_series_only=True, trim_zero_exposure=False, use_barycenter=False,
+                        quiet=True)
+    assert len(_n(ts.starts)) > 3_700_000
+    f, p0, p1, pb = core.power_spectrum_fft(ts)
+    assert len(f) == (1 << 23) + 1
+    with np.errstate(all='ignore'):
+        rf, r0, r1, rb = orc.power_spectrum_fft(_n(ts.starts), _n(ts.stops), _n(ts.counts), _n(ts.weights),
+                                                _n(ts.weights2), _n(ts.sexp), _n(ts.bexp))
+    assert np.array_equal(f, rf)
+    for got, ref, nm in ((p0, r0, 'P0'), (p1, r1, 'P1'), (pb, rb, 'Pb')):
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), fin), nm
+        tol = RTOL * np.maximum(np.abs(ref[fin]), 1e-3 * np.abs(ref[fin]).max())
+        assert (np.abs(got[fin] - ref[fin]) <= tol).all(), (nm, np.abs(got[fin] - ref[fin]).max())
