@@ -113,6 +113,32 @@ def fit_cells_sharded(counts, fit_fn, group=None):
     return all_gather_ragged(rec, sizes=sizes, group=group)
 
 
+def search_topk_sharded(nf, search_fn, k=10, group=None):
+    """The k largest values of the statistic over nf trial frequencies and their
+    global frequency indices, on every rank: each rank searches its slice
+    (search_fn(j0, n) -> (n,) tensor), keeps its own k best, and one all-gather of
+    2 k doubles per rank is reduced to the global k best.  Returns (values,
+    indices) as host arrays, largest first; ties go to the lower index."""
+    rank, world = _world(group)
+    j0, n = frequency_shard(nf, group=group)
+    z = search_fn(j0, n)
+    kk = min(k, n)
+    rec = torch.full((k, 2), -np.inf, dtype=torch.float64, device=z.device)
+    rec[:, 1] = -1.0
+    if kk > 0:
+        v, i = torch.topk(z, kk)
+        rec[:kk, 0] = v.to(torch.float64)
+        rec[:kk, 1] = (i + j0).to(torch.float64)
+    if world > 1:
+        allrec = torch.empty((world * k, 2), dtype=torch.float64, device=rec.device)
+        dist.all_gather_into_tensor(allrec, rec.contiguous(), group=group)
+        rec = allrec
+    r = rec.cpu().numpy()
+    r = r[r[:, 1] >= 0]
+    order = np.lexsort((r[:, 1], -r[:, 0]))[:k]
+    return r[order, 0], r[order, 1].astype(np.int64)
+
+
 def search_sharded(nf, search_fn, gather_spectrum=False, group=None):
     """Run search_fn(j0, n) -> (n,) statistic tensor on this rank's slice of nf
     trial frequencies.  Returns (global_max, global_argmax) and, if

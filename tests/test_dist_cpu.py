@@ -63,6 +63,9 @@ def _worker(rank, world, port, q):
         full = orc.z2m(t, w, 1e-3, 2e-7, nf, m=2)
         ok2 = (jmax == int(np.argmax(full))) and (zmax == full.max()) and \
             np.array_equal(spec.numpy(), full)
+        tv, ti_ = gd.search_topk_sharded(nf, search_fn, k=7)
+        want = np.lexsort((np.arange(nf), -full))[:7]
+        ok2 = ok2 and np.array_equal(ti_, want) and np.array_equal(tv, full[want])
         # the same search with the photons split over the ranks: sums are all-reduced
         p0, p1 = gd.photon_shard(len(t))
 
