@@ -20,11 +20,12 @@ namespace {
 constexpr double TWO_PI_HI = 6.283185307179586232e+00;
 constexpr double TWO_PI_LO = 2.449293598294706414e-16;
 
-// sin(2 pi x), cos(2 pi x) for |x| <= 0.5 (x in cycles).  Quadrant folding to
-// |r| <= 1/8, then the classic minimax kernels on |theta| <= pi/4.
+// sin(2 pi x), cos(2 pi x) for x in cycles, |x| up to a few turns (the quarter
+// turns are folded exactly).  Quadrant folding to |r| <= 1/8, then the classic
+// minimax kernels on |theta| <= pi/4.
 __device__ __forceinline__ void sincos_cycles(double x, double &s, double &c)
 {
-    double q = rint(4.0 * x);            // -2..2
+    double q = rint(4.0 * x);            // a small integer
     double r = fma(q, -0.25, x);         // exact
     double th = fma(r, TWO_PI_HI, r * TWO_PI_LO);
     double z = th * th;
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const double *w, int64_t n,
 }
 
 constexpr int Z_THREADS = 256;
+#ifndef Z_AHEAD
+#define Z_AHEAD 4
+#endif
 
 // Frequencies per thread.  The sin/cos of a thread's first frequency costs
 // about 50 instructions per photon, a further frequency 4 (m = 1), 7 (m = 2)
@@ -137,13 +141,13 @@ template <int M, int J, bool SQ>
 __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ rows, int64_t i0, int64_t i1,
                                                double jb, double (&acc)[J][M][2])
 {
-    for (int64_t i = i0; i < i1; ++i) {
-        const PhotonRow r = rows[i];           // wave-uniform address: scalar load
+    // one photon: all J frequencies of this thread
+    auto one = [&](const PhotonRow &r) {
         // phase of this thread's first frequency: a + frac(jb * u), u = uh + ul
         double p = jb * r.uh;
         double e = fma(jb, r.uh, -p);
-        double x = (p - rint(p)) + fma(jb, r.ul, e) + r.a;
-        x -= rint(x);
+        // |x| <= 1.5: sincos_cycles folds whole quarter turns itself
+        const double x = (p - rint(p)) + fma(jb, r.ul, e) + r.a;
         double s, c;
         sincos_cycles(x, s, c);
         if constexpr (SQ) {
@@ -168,7 +172,7 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
                     s = sn;
                 }
             }
-            continue;
+            return;
         }
         double cp = fma(c, r.cd, s * r.sd), sp = fma(s, r.cd, -(c * r.sd));
 #pragma unroll
@@ -195,7 +199,19 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
                 s = sn;
             }
         }
+    };
+    // The rows come by wave-uniform (scalar) loads.  Z_AHEAD of them are requested
+    // together, so the wavefront waits out the load latency once per group and not
+    // once per photon (at two wavefronts per SIMD nobody else hides it).
+    int64_t i = i0;
+    for (; i + Z_AHEAD <= i1; i += Z_AHEAD) {
+        PhotonRow r[Z_AHEAD];
+#pragma unroll
+        for (int u = 0; u < Z_AHEAD; ++u) r[u] = rows[i + u];
+#pragma unroll
+        for (int u = 0; u < Z_AHEAD; ++u) one(r[u]);
     }
+    for (; i < i1; ++i) one(rows[i]);
     if constexpr (SQ) {
 #pragma unroll
         for (int k = 0; k < J; ++k) acc[k][1][1] += acc[k][1][1];
