@@ -278,9 +278,9 @@ def main():
         z_ms = event_time_ms(lambda: ops.z2m(zt, zw, f0, df, nf, m=2, workspace=ws), 3, stream)
         evals = float(zt.numel()) * nf / (z_ms * 1e-3)
         extra['z2m'] = dict(photon_freq_evals_per_s=evals, ms=z_ms, nph=zt.numel(), nfreq=nf, m=2,
-                            nominal_flops_per_eval=45, executed_valu_instr_per_eval=9.5,
+                            nominal_flops_per_eval=45, executed_valu_instr_per_eval=9.4,
                             nominal_frac_of_fp64_peak=45 * evals / (FP64_PEAK_TFLOPS * 1e12),
-                            executed_frac_of_fp64_issue=2 * 9.5 * evals / (FP64_PEAK_TFLOPS * 1e12))
+                            executed_frac_of_fp64_issue=2 * 9.4 * evals / (FP64_PEAK_TFLOPS * 1e12))
         del ws
         torch.cuda.empty_cache()
         # power_spectrum_fft at the C3 size: 3 786 912 bins of 100 s -> l = 2^25
