@@ -333,6 +333,26 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
                 of[u] = swap ? av[u] : 1.0;
             }
             int64_t j = j0;
+            // 32 photons per trip: four scalar loads go out together and their latency
+            // (the whole cell streams from HBM) is waited out once, not once per eight photons
+            for (; j + 32 <= j1; j += 32) {
+                double wv[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) wv[k] = w[j + k];
+#pragma unroll
+                for (int g = 0; g < 32; g += 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                        for (int u = 0; u < BK_PPL; ++u) pr[u] *= fma(sg[u], wv[g + k], of[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < BK_PPL; ++u) {
+                        ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                        pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                    }
+                }
+            }
             for (; j + 8 <= j1; j += 8) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
