@@ -46,28 +46,46 @@ __device__ __forceinline__ double linspace_at(double a0, double a1, double step,
     return (double)i * step + a0;
 }
 
+// uniform[c] = 1 when the abscissae of cell c are, to the bit, numpy.linspace of their
+// end points (what get_logpdf produces): the fitness kernel then computes them instead
+// of loading them
+__global__ void bb_uniform_kernel(const double *__restrict__ dom, int64_t ncell, int npt, int32_t *uniform)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const double *xp = dom + c * npt;
+    const double x0 = xp[0], xl = xp[npt - 1];
+    const double step = (xl - x0) / (double)(npt - 1);
+    int ok = 1;
+    for (int j = 0; j < npt; ++j) ok &= (xp[j] == linspace_at(x0, xl, step, j, npt)) ? 1 : 0;
+    uniform[c] = ok;
+}
+
 // numpy.interp(x, xp, fp, left=-inf, right=-inf) for one x; xp is a uniform
 // grid (numpy.linspace), so the interval is guessed arithmetically and then
-// settled by the comparisons numpy's search makes.
+// settled by the comparisons numpy's search makes.  UNI: the abscissae are
+// known to equal linspace(x0, xl, npt) exactly and are computed, not loaded.
+template <bool UNI>
 __device__ __forceinline__ double interp_one(double x, const double *__restrict__ xp,
                                              const double *__restrict__ fp, const double *__restrict__ sl,
-                                             int npt, double x0, double xl, double inv_step)
+                                             int npt, double x0, double xl, double inv_step, double step)
 {
     if (isnan(x)) return x;
     if (x < x0 || x > xl) return -INFINITY;
     if (x == xl) return fp[npt - 1];
     int j = (int)((x - x0) * inv_step);
     j = j < 0 ? 0 : (j > npt - 2 ? npt - 2 : j);
-    double xj = xp[j], xj1 = xp[j + 1];
+    auto at = [&](int q) { return UNI ? linspace_at(x0, xl, step, q, npt) : xp[q]; };
+    double xj = at(j), xj1 = at(j + 1);
     while (j > 0 && x < xj) {
         --j;
         xj1 = xj;
-        xj = xp[j];
+        xj = at(j);
     }
     while (j < npt - 2 && x >= xj1) {
         ++j;
         xj = xj1;
-        xj1 = xp[j + 1];
+        xj1 = at(j + 1);
     }
     const double fj = fp[j];
     if (xj == x) return fj;
@@ -101,6 +119,7 @@ __device__ __forceinline__ Best best_of(Best a, Best b)
 __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__restrict__ dom,
                                                                 const double *__restrict__ cod,
                                                                 const double *__restrict__ slopes,
+                                                                const int32_t *__restrict__ uniform,
                                                                 int64_t ncell, int npt, int ngrid,
                                                                 int64_t row_begin, int64_t row_end,
                                                                 double *__restrict__ fit_val,
@@ -125,13 +144,25 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
         const double *xp = dom + c * npt, *fp = cod + c * npt, *sl = slopes + c * npt;
         const double x0 = xp[0], xl = xp[npt - 1];
         const double inv_step = (double)(npt - 1) / (xl - x0);
+        const double step = (xl - x0) / (double)(npt - 1);
         Best b{-INFINITY, ngrid};
+        if (uniform[c]) {                       // the same for the whole workgroup
 #pragma unroll
-        for (int u = 0; u < BB_PPT; ++u) {
-            const int k = u * BB_THREADS + tid;
-            if (k < ngrid) {
-                acc[u] += interp_one(x[u], xp, fp, sl, npt, x0, xl, inv_step);
-                b = best_of(b, Best{acc[u], k});
+            for (int u = 0; u < BB_PPT; ++u) {
+                const int k = u * BB_THREADS + tid;
+                if (k < ngrid) {
+                    acc[u] += interp_one<true>(x[u], xp, fp, sl, npt, x0, xl, inv_step, step);
+                    b = best_of(b, Best{acc[u], k});
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < BB_PPT; ++u) {
+                const int k = u * BB_THREADS + tid;
+                if (k < ngrid) {
+                    acc[u] += interp_one<false>(x[u], xp, fp, sl, npt, x0, xl, inv_step, step);
+                    b = best_of(b, Best{acc[u], k});
+                }
             }
         }
 #pragma unroll
@@ -231,7 +262,8 @@ __global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__rest
 extern "C" size_t godot_bb_workspace_bytes(int64_t ncell, int npt)
 {
     if (ncell < 0 || npt < 0) return 0;
-    return (size_t)ncell * (size_t)npt * sizeof(double);
+    // slopes, then one flag per cell
+    return (size_t)ncell * (size_t)npt * sizeof(double) + (size_t)ncell * sizeof(int32_t);
 }
 
 extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt, int ngrid,
@@ -252,8 +284,12 @@ extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t nc
     double *slopes = (double *)workspace;
     hipLaunchKernelGGL(bb_slopes_kernel, dim3((unsigned)ceil_div(ncell * npt, 256)), dim3(256), 0, st, dom, cod,
                        ncell, npt, slopes);
+    int32_t *uniform = (int32_t *)(slopes + (size_t)ncell * (size_t)npt);
+    hipLaunchKernelGGL(bb_uniform_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, dom, ncell, npt,
+                       uniform);
     hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)(row_end - row_begin)), dim3(BB_THREADS), 0, st, dom,
-                       cod, (const double *)slopes, ncell, npt, ngrid, row_begin, row_end, fit_val, fit_arg);
+                       cod, (const double *)slopes, (const int32_t *)uniform, ncell, npt, ngrid, row_begin,
+                       row_end, fit_val, fit_arg);
     GODOT_LAUNCH_CHECK("godot_bb_fitness");
     return GODOT_OK;
 }

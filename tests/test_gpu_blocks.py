@@ -82,13 +82,19 @@ def test_bb_pipeline_matches_reference(golden):
 
 
 def test_fitness_matches_oracle_on_random_profiles():
-    """Ragged supports (many -inf sums), NaN rows, a grid that is not 1000 points."""
+    """Ragged supports (many -inf sums), NaN rows, non-uniform abscissae, a grid that is not
+    1000 points."""
     from godot_amd import ops
     rng = np.random.default_rng(5)
     n, npt = 300, 64
     lo = rng.uniform(0, 2, n)
     hi = lo + rng.uniform(0.05, 3, n)
     dom = np.linspace(lo, hi, npt).T.copy()
+    # every fifth cell on abscissae that are not a linspace: the kernel must then load them
+    # (it computes the abscissae of cells whose rows equal numpy.linspace to the bit)
+    warped = np.arange(n) % 5 == 3
+    u = np.linspace(0, 1, npt) ** 1.3
+    dom[warped] = lo[warped, None] + (hi - lo)[warped, None] * u[None, :]
     peak = rng.uniform(lo, hi)
     cod = -((dom - peak[:, None]) * rng.uniform(1, 6, n)[:, None]) ** 2
     cod -= cod.max(axis=1, keepdims=True)
