@@ -27,16 +27,17 @@ constexpr int BB_PPT = 4;                       // grid points per thread
 constexpr int BB_MAX_GRID = BB_THREADS * BB_PPT;
 constexpr int BB_RING = 32;                     // cells between two cross-wavefront reductions
 
-// slopes[c][j] = (cod[c][j+1] - cod[c][j]) / (dom[c][j+1] - dom[c][j])  (numpy's arr_interp)
+// pairs[c][j] = (cod[c][j], slope) with slope = (cod[c][j+1] - cod[c][j]) / (dom[c][j+1] - dom[c][j])
+// (numpy's arr_interp): the value and the slope of an interval come with one 16-byte load
 __global__ void bb_slopes_kernel(const double *__restrict__ dom, const double *__restrict__ cod, int64_t ncell,
-                                 int npt, double *__restrict__ slopes)
+                                 int npt, double2 *__restrict__ pairs)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncell * npt) return;
     const int j = (int)(k % npt);
     double s = 0.0;
     if (j + 1 < npt) s = (cod[k + 1] - cod[k]) / (dom[k + 1] - dom[k]);
-    slopes[k] = s;
+    pairs[k] = make_double2(cod[k], s);
 }
 
 // numpy.linspace(a0, a1, n)[i]
@@ -67,12 +68,12 @@ __global__ void bb_uniform_kernel(const double *__restrict__ dom, int64_t ncell,
 // known to equal linspace(x0, xl, npt) exactly and are computed, not loaded.
 template <bool UNI>
 __device__ __forceinline__ double interp_one(double x, const double *__restrict__ xp,
-                                             const double *__restrict__ fp, const double *__restrict__ sl,
-                                             int npt, double x0, double xl, double inv_step, double step)
+                                             const double2 *__restrict__ fs, int npt, double x0, double xl,
+                                             double inv_step, double step)
 {
     if (isnan(x)) return x;
     if (x < x0 || x > xl) return -INFINITY;
-    if (x == xl) return fp[npt - 1];
+    if (x == xl) return fs[npt - 1].x;
     int j = (int)((x - x0) * inv_step);
     j = j < 0 ? 0 : (j > npt - 2 ? npt - 2 : j);
     auto at = [&](int q) { return UNI ? linspace_at(x0, xl, step, q, npt) : xp[q]; };
@@ -87,12 +88,13 @@ __device__ __forceinline__ double interp_one(double x, const double *__restrict_
         xj = xj1;
         xj1 = at(j + 1);
     }
-    const double fj = fp[j];
+    const double2 v = fs[j];
+    const double fj = v.x;
     if (xj == x) return fj;
-    const double s = sl[j];
+    const double s = v.y;
     double r = s * (x - xj) + fj;
     if (isnan(r)) {
-        const double fj1 = fp[j + 1];
+        const double fj1 = fs[j + 1].x;
         r = s * (x - xj1) + fj1;
         if (isnan(r) && fj == fj1) r = fj;
     }
@@ -117,8 +119,7 @@ __device__ __forceinline__ Best best_of(Best a, Best b)
 // Row i (cells 0 .. i): fit_val / fit_arg[i (i + 1) / 2 + j] = 2 * (max over the grid, alpha
 // there) of the summed profiles of cells j .. i  (core.py:1108-1136 with i0 = 0, i1 = i + 1).
 __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__restrict__ dom,
-                                                                const double *__restrict__ cod,
-                                                                const double *__restrict__ slopes,
+                                                                const double2 *__restrict__ pairs,
                                                                 const int32_t *__restrict__ uniform,
                                                                 int64_t ncell, int npt, int ngrid,
                                                                 int64_t row_begin, int64_t row_end,
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
     const int64_t obase = i * (i + 1) / 2 - row_begin * (row_begin + 1) / 2;
     int pending = 0;
     for (int64_t c = i; c >= 0; --c) {
-        const double *xp = dom + c * npt, *fp = cod + c * npt, *sl = slopes + c * npt;
+        const double *xp = dom + c * npt;
+        const double2 *fs = pairs + c * npt;
         const double x0 = xp[0], xl = xp[npt - 1];
         const double inv_step = (double)(npt - 1) / (xl - x0);
         const double step = (xl - x0) / (double)(npt - 1);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
             for (int u = 0; u < BB_PPT; ++u) {
                 const int k = u * BB_THREADS + tid;
                 if (k < ngrid) {
-                    acc[u] += interp_one<true>(x[u], xp, fp, sl, npt, x0, xl, inv_step, step);
+                    acc[u] += interp_one<true>(x[u], xp, fs, npt, x0, xl, inv_step, step);
                     b = best_of(b, Best{acc[u], k});
                 }
             }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
             for (int u = 0; u < BB_PPT; ++u) {
                 const int k = u * BB_THREADS + tid;
                 if (k < ngrid) {
-                    acc[u] += interp_one<false>(x[u], xp, fp, sl, npt, x0, xl, inv_step, step);
+                    acc[u] += interp_one<false>(x[u], xp, fs, npt, x0, xl, inv_step, step);
                     b = best_of(b, Best{acc[u], k});
                 }
             }
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__rest
 extern "C" size_t godot_bb_workspace_bytes(int64_t ncell, int npt)
 {
     if (ncell < 0 || npt < 0) return 0;
-    // slopes, then one flag per cell
-    return (size_t)ncell * (size_t)npt * sizeof(double) + (size_t)ncell * sizeof(int32_t);
+    // (value, slope) pairs, then one flag per cell
+    return (size_t)ncell * (size_t)npt * sizeof(double2) + (size_t)ncell * sizeof(int32_t);
 }
 
 extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt, int ngrid,
@@ -281,15 +283,15 @@ extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t nc
     GODOT_REQUIRE(dom && cod && workspace && fit_val && fit_arg, GODOT_E_INVALID,
                   "godot_bb_fitness: null argument");
     hipStream_t st = (hipStream_t)stream;
-    double *slopes = (double *)workspace;
+    double2 *pairs = (double2 *)workspace;
     hipLaunchKernelGGL(bb_slopes_kernel, dim3((unsigned)ceil_div(ncell * npt, 256)), dim3(256), 0, st, dom, cod,
-                       ncell, npt, slopes);
-    int32_t *uniform = (int32_t *)(slopes + (size_t)ncell * (size_t)npt);
+                       ncell, npt, pairs);
+    int32_t *uniform = (int32_t *)(pairs + (size_t)ncell * (size_t)npt);
     hipLaunchKernelGGL(bb_uniform_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, dom, ncell, npt,
                        uniform);
     hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)(row_end - row_begin)), dim3(BB_THREADS), 0, st, dom,
-                       cod, (const double *)slopes, (const int32_t *)uniform, ncell, npt, ngrid, row_begin,
-                       row_end, fit_val, fit_arg);
+                       (const double2 *)pairs, (const int32_t *)uniform, ncell, npt, ngrid, row_begin, row_end,
+                       fit_val, fit_arg);
     GODOT_LAUNCH_CHECK("godot_bb_fitness");
     return GODOT_OK;
 }
