@@ -15,8 +15,9 @@
 // formed once per cell by a kernel of their own, with the same IEEE division,
 // so the interpolated values are the reference's to the last bit (this file
 // is compiled without FMA contraction: numpy multiplies, rounds, then adds).
-// The dynamic programme over the rows (core.py:1146-1161) runs in a single
-// workgroup, 64 rows at a time (see bb_partition_kernel).
+// The dynamic programme over the rows (core.py:1146-1161) goes in blocks of 1024 rows:
+// the candidates below a block on all CUs, those inside it in one workgroup, 64 rows
+// at a time (see bb_below_kernel / bb_within_kernel).
 
 #include "common.hpp"
 
@@ -198,35 +199,84 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
 
 // best[0] = 0; best[i+1] = max over r <= i of (fit_val[row i][r] - prior) + best[r];
 // last[i] = the first r that attains it  (core.py:1146-1161).
-// The recurrence is sequential in i, but row i needs best[r] of the current
-// stretch of 64 rows only for r inside the stretch: the candidates r below the
-// stretch are reduced for all its rows at once by the sixteen wavefronts, the
-// candidates inside it by one wavefront row after row without a barrier.
+// The recurrence is sequential in i, but row i needs best[r] only for r <= i:
+// the rows are taken in blocks of BP_BLOCK.  For a block starting at i0,
+//   bb_below_kernel   (one workgroup per row, all CUs): the candidates r < i0,
+//                     whose best[r] are final -- the bulk of the ncell^2 / 2
+//                     compare-adds and of the bytes read; its result is parked
+//                     in best[i + 1] / last[i], which are not final yet;
+//   bb_within_kernel  (one workgroup): the candidates i0 <= r <= i, in
+//                     stretches of 64 rows: those below the stretch are
+//                     reduced for all its rows at once by the sixteen
+//                     wavefronts, those inside it by one wavefront row after
+//                     row without a barrier.
 constexpr int BP_K = 64;
+constexpr int BP_BLOCK = 1024;
+constexpr int BP_NONE = 0x7fffffff;
 
-__global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__restrict__ fit_val, int64_t ncell,
-                                                            double prior, double *best, int64_t *last)
+__global__ __launch_bounds__(256) void bb_below_kernel(const double *__restrict__ fit_val, int64_t i0, double prior,
+                                                       double *best, int64_t *last)
+{
+    __shared__ double s_v[4];
+    __shared__ int s_k[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t i = i0 + blockIdx.x;
+    const double *row = fit_val + i * (i + 1) / 2;
+    Best b{-INFINITY, BP_NONE};
+    for (int64_t r = tid; r < i0; r += 256) b = best_of(b, Best{(row[r] - prior) + best[r], (int)r});
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+        b = best_of(b, other);
+    }
+    if (lane == 0) {
+        s_v[wave] = b.v;
+        s_k[wave] = b.k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) b = best_of(b, Best{s_v[w], s_k[w]});
+        best[i + 1] = b.v;
+        last[i] = b.k;
+    }
+}
+
+// value and first lane of the maximum over a wavefront, in numpy.argmax's order (a NaN
+// beats everything, ties go to the lower lane): one max-reduction and two ballots
+__device__ __forceinline__ Best wave_best_by_lane(double v, int base)
+{
+    const unsigned long long nan_lanes = __ballot(isnan(v) ? 1 : 0);
+    if (nan_lanes) return Best{qnan(), base + (int)__builtin_ctzll(nan_lanes)};
+    const double m = team_max<64>(v);
+    const unsigned long long at = __ballot(v == m ? 1 : 0);
+    return Best{m, base + (int)__builtin_ctzll(at)};
+}
+
+__global__ __launch_bounds__(1024) void bb_within_kernel(const double *__restrict__ fit_val, int64_t ncell,
+                                                         int64_t b0, int64_t b1, double prior, double *best,
+                                                         int64_t *last)
 {
     __shared__ double s_v[BP_K];
     __shared__ int s_k[BP_K];
     __shared__ double s_best[BP_K + 1];       // best[i0 .. i0 + 64] of the stretch
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) best[0] = 0.0;
+    if (b0 == 0 && tid == 0) best[0] = 0.0;
     __syncthreads();
-    for (int64_t i0 = 0; i0 < ncell; i0 += BP_K) {
-        const int kmax = (int)((ncell - i0) < BP_K ? (ncell - i0) : BP_K);
-        // candidates below the stretch
+    for (int64_t i0 = b0; i0 < b1; i0 += BP_K) {
+        const int kmax = (int)((b1 - i0) < BP_K ? (b1 - i0) : BP_K);
+        // candidates of this block below the stretch, on top of what bb_below_kernel parked
         for (int t = wave; t < kmax; t += 16) {
             const int64_t i = i0 + t;
             const double *row = fit_val + i * (i + 1) / 2;
-            Best b{-INFINITY, 0x7fffffff};
-            for (int64_t r = lane; r < i0; r += 64) b = best_of(b, Best{(row[r] - prior) + best[r], (int)r});
+            Best b{-INFINITY, BP_NONE};
+            for (int64_t r = b0 + lane; r < i0; r += 64) b = best_of(b, Best{(row[r] - prior) + best[r], (int)r});
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
                 b = best_of(b, other);
             }
             if (lane == 0) {
+                if (b0 > 0) b = best_of(Best{best[i + 1], (int)last[i]}, b);
                 s_v[t] = b.v;
                 s_k[t] = b.k;
             }
@@ -238,14 +288,11 @@ __global__ __launch_bounds__(1024) void bb_partition_kernel(const double *__rest
             for (int t = 0; t < kmax; ++t) {
                 const int64_t i = i0 + t;
                 const double *row = fit_val + i * (i + 1) / 2;
-                Best b{s_v[t], s_k[t]};
-                if (lane <= t) b = best_of(b, Best{(row[i0 + lane] - prior) + s_best[lane], (int)(i0 + lane)});
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
-                    b = best_of(b, other);
-                }
-                if (b.k == 0x7fffffff) b.k = 0;
+                double v = -INFINITY;
+                if (lane <= t) v = (row[i0 + lane] - prior) + s_best[lane];
+                // lanes are in the order of r: the first lane of the maximum is its first r
+                Best b = best_of(Best{s_v[t], s_k[t]}, wave_best_by_lane(v, (int)i0));
+                if (b.k == BP_NONE) b.k = 0;
                 if (lane == 0) {
                     s_best[t + 1] = b.v;
                     best[i + 1] = b.v;
@@ -303,8 +350,15 @@ extern "C" int godot_bb_partition(const double *fit_val, int64_t ncell, double p
     GODOT_REQUIRE(ncell < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_bb_partition: too many cells");
     if (ncell == 0) return GODOT_OK;
     GODOT_REQUIRE(fit_val && best && last, GODOT_E_INVALID, "godot_bb_partition: null argument");
-    hipLaunchKernelGGL(bb_partition_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, fit_val, ncell, prior,
-                       best, last);
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t b0 = 0; b0 < ncell; b0 += BP_BLOCK) {
+        const int64_t b1 = b0 + BP_BLOCK < ncell ? b0 + BP_BLOCK : ncell;
+        if (b0 > 0)
+            hipLaunchKernelGGL(bb_below_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0, st, fit_val, b0, prior,
+                               best, last);
+        hipLaunchKernelGGL(bb_within_kernel, dim3(1), dim3(1024), 0, st, fit_val, ncell, b0, b1, prior, best,
+                           last);
+    }
     GODOT_LAUNCH_CHECK("godot_bb_partition");
     return GODOT_OK;
 }

@@ -47,6 +47,30 @@ def test_partition_equals_reference(golden, prior, key):
     assert np.array_equal(idx, g[key + '_indices'])
 
 
+@pytest.mark.parametrize('variant', ['ties', 'smooth', 'nan'])
+def test_partition_over_several_blocks_of_rows(variant):
+    """More rows than one block of the dynamic programme holds (the candidates below a
+    block are reduced by a kernel of their own): best and last against the oracle, with
+    many exact ties, -inf entries and a NaN."""
+    from godot_amd import ops
+    rng = np.random.default_rng(len(variant))
+    n = 2500
+    tri = n * (n + 1) // 2
+    if variant == 'ties':
+        fv = np.round(rng.normal(0, 3, tri), 0)          # integers: ties everywhere
+        fv[rng.random(tri) < 0.05] = -np.inf
+    else:
+        fv = rng.normal(0, 3, tri) + 0.01 * np.arange(tri) / n
+    if variant == 'nan':
+        fv[1800 * 1801 // 2 + 700] = np.nan
+    rows = [fv[i * (i + 1) // 2:(i + 1) * (i + 2) // 2] for i in range(n)]
+    with np.errstate(all='ignore'):
+        idx, best_ref, best_all, last_ref = orc.bb_partition(rows, 2.5)
+    best, last = ops.bb_partition(_d(fv), n, 2.5)
+    assert np.array_equal(last.cpu().numpy(), last_ref)
+    assert np.array_equal(best.cpu().numpy(), best_all, equal_nan=True)
+
+
 def test_bb_pipeline_matches_reference(golden):
     """Profiles, fitness rows, partition, merged cells and their fluxes all on the
     device, against the reference's get_bb_lightcurve."""
