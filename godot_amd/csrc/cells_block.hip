@@ -7,22 +7,129 @@
 // branches are uniform.  The schedule itself (get_max, get_ts, the support
 // search and the profile grid of get_logpdf) is the shared code of
 // cells_common.hpp.
+//
+// When the cells are fewer than the compute units, each cell is spread over G
+// workgroups (one per compute unit, launched cooperatively so that all of them
+// are resident): a workgroup streams its share of the photons, publishes its
+// partial sums in a slot of device memory, waits for the other G - 1 at a
+// barrier of the cell's own, and adds the G partial results in a fixed order, so
+// that every workgroup of a cell holds the same bits and walks the same path
+// through the schedule.  One compute unit streams at most some tens of GB/s;
+// a cell of millions of photons needs many of them.
 
 #include "cells_common.hpp"
+
+#include <mutex>
 
 namespace {
 
 constexpr int BK_THREADS = 1024;
 constexpr int BK_WAVES = BK_THREADS / 64;
 
+// spread cells: workgroups per cell, slots, barrier counters
+constexpr int SP_MAX_G = 64;          // workgroups per cell
+constexpr int SP_MAX_WG = 512;        // workgroups per launch
+constexpr int SP_SLOT = 4;            // doubles a workgroup publishes per exchange
+constexpr int64_t SP_MIN_SHARE = 8192;   // photons per workgroup below which spreading does not pay
+constexpr long SP_SPIN_LIMIT = 1L << 22;
+
+// Partial results of the workgroups (two generations, so that a workgroup may
+// publish exchange k + 1 while another still reads exchange k) and one arrival
+// counter per cell.  One copy per device; launches that use it are ordered by
+// the host (spread_order below).
+__device__ double g_sp_slots[2 * SP_MAX_WG * SP_SLOT];
+__device__ unsigned g_sp_count[SP_MAX_WG];
+
+__global__ void spread_reset_kernel()
+{
+    for (int i = threadIdx.x; i < SP_MAX_WG; i += blockDim.x) g_sp_count[i] = 0u;
+}
+
+// What a workgroup of a spread cell needs to talk to the others.
+struct Spread {
+    double *slots;     // this launch's slots: [2][ncell * G][SP_SLOT]
+    unsigned *count;   // this cell's arrival counter
+    int64_t first;     // index of the cell's first workgroup among the launch's
+    int g, G;
+    double *xs;        // LDS: SP_SLOT * SP_MAX_G doubles
+    int *broken;       // LDS: set when a barrier timed out
+};
+
 // The cell as the whole workgroup sees it.  Same interface as CellData.
-struct BlockCell {
+// SPREAD: p, n describe this workgroup's share of the cell and every reduction
+// ends with an exchange between the cell's workgroups.
+template <bool SPREAD>
+struct BlockCellT {
     const double *p;
     int64_t n;
     int tid;
     bool swap;
     double *red;       // LDS: 3 * BK_WAVES doubles
     int *redi;         // LDS: BK_WAVES ints
+    Spread sp;
+    mutable unsigned gen = 0;
+
+    // Publishes NS values (the same in every thread), waits for all workgroups
+    // of the cell and leaves value k of workgroup j in sp.xs[k * G + j].
+    template <int NS>
+    __device__ __forceinline__ void gather(const double (&v)[NS]) const
+    {
+        static_assert(NS <= SP_SLOT, "slot too small");
+        const int G = sp.G;
+        double *gen_slots = sp.slots + (size_t)(gen & 1u) * SP_MAX_WG * SP_SLOT;
+        if (tid == 0) {
+            double *mine = gen_slots + (sp.first + sp.g) * SP_SLOT;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                __hip_atomic_store(mine + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sp.count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (gen + 1u) * (unsigned)G;
+            if (!*sp.broken) {
+                long spins = 0;
+                while (__hip_atomic_load(sp.count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > SP_SPIN_LIMIT) {   // never on a cooperative launch; ends a broken one
+                        *sp.broken = 1;
+                        break;
+                    }
+                }
+            }
+        }
+        ++gen;
+        __syncthreads();
+        if (tid < NS * G) {
+            const int k = tid / G, j = tid - k * G;
+            sp.xs[tid] = __hip_atomic_load(gen_slots + (sp.first + j) * SP_SLOT + k, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+
+    template <int NS>
+    __device__ __forceinline__ void spread_sum(double (&acc)[NS]) const
+    {
+        gather<NS>(acc);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < sp.G; ++j) s += sp.xs[k * sp.G + j];
+            acc[k] = s;
+        }
+    }
+
+    // product of the workgroups' mantissas in xs[m0 * G ..] and sum of their
+    // exponents in xs[e0 * G ..]
+    __device__ __forceinline__ void spread_prod_from(int m0, int e0, double &pr, int &ex) const
+    {
+        double m = 1.0;
+        int e = 0;
+        for (int j = 0; j < sp.G; ++j) {       // at most 64 factors in [0.5, 1)
+            m *= sp.xs[m0 * sp.G + j];
+            e += (int)sp.xs[e0 * sp.G + j];
+        }
+        ex = e + __builtin_amdgcn_frexp_exp(m);
+        pr = __builtin_amdgcn_frexp_mant(m);
+    }
 
     __device__ __forceinline__ double ld(int64_t i) const
     {
@@ -101,6 +208,7 @@ struct BlockCell {
             accf(wv, d, rcp_fast1(d), acc);
         }
         block_sum<NS>(acc);
+        if constexpr (SPREAD) spread_sum<NS>(acc);
     }
 
     template <class DEN, class GF>
@@ -137,6 +245,14 @@ struct BlockCell {
         pr = __builtin_amdgcn_frexp_mant(pr);
         block_prod(pr, ex);
         block_sum<1>(gs);
+        if constexpr (SPREAD) {
+            const double v[3] = {pr, (double)ex, gs[0]};
+            gather<3>(v);
+            spread_prod_from(0, 1, pr, ex);
+            double sg = 0.0;
+            for (int j = 0; j < sp.G; ++j) sg += sp.xs[2 * sp.G + j];
+            gs[0] = sg;
+        }
         gsum = gs[0];
         logs = log_mant(pr, ex);
     }
@@ -187,6 +303,12 @@ struct BlockCell {
         p2 = __builtin_amdgcn_frexp_mant(p2);
         block_prod(p1, e1);
         block_prod(p2, e2);
+        if constexpr (SPREAD) {
+            const double v[4] = {p1, (double)e1, p2, (double)e2};
+            gather<4>(v);
+            spread_prod_from(0, 1, p1, e1);
+            spread_prod_from(2, 3, p2, e2);
+        }
         return log_scaled(p1 * rcp_fast(p2), e1 - e2);
     }
 
@@ -206,9 +328,18 @@ struct BlockCell {
 #pragma unroll
         for (int w = 0; w < BK_WAVES; ++w) r = fmax(r, red[w]);
         __syncthreads();
+        if constexpr (SPREAD) {
+            const double v[1] = {r};
+            gather<1>(v);
+            r = -INFINITY;
+            for (int j = 0; j < sp.G; ++j) r = fmax(r, sp.xs[j]);
+        }
         return r;
     }
 };
+
+using BlockCell = BlockCellT<false>;
+using SpreadCell = BlockCellT<true>;
 
 // a value every lane holds alike, as a scalar
 __device__ __forceinline__ int64_t uniform_i64(int64_t v)
@@ -245,7 +376,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_block_kernel(CellArgs p, 
     __shared__ int s_redi[BK_WAVES];
     const int64_t cell = blockIdx.x;
     const BlockSetup b = block_setup(p, cell);
-    BlockCell cd{p.we + b.lo, b.n, (int)threadIdx.x, p.swap != 0, s_red, s_redi};
+    BlockCell cd{p.we + b.lo, b.n, (int)threadIdx.x, p.swap != 0, s_red, s_redi, {}};
     int fl = 0;
     double a = qnan(), t = qnan();
     if (b.bad) {
@@ -286,7 +417,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
     const int64_t cell = blockIdx.x;
     const bool swap = p.swap != 0;
     const BlockSetup b = block_setup(p, cell);
-    BlockCell cd{p.we + b.lo, b.n, tid, swap, s_red, s_redi};
+    BlockCell cd{p.we + b.lo, b.n, tid, swap, s_red, s_redi, {}};
     int fl = 0;
     bool ok = !b.bad;
     double aopt = qnan();
@@ -450,6 +581,277 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
     if (flags && tid == 0) flags[cell] = fl;
 }
 
+// ---------------------------------------------------------------------------
+// Spread cells: G workgroups per cell (cooperative launch)
+// ---------------------------------------------------------------------------
+
+struct SpreadSetup {
+    BlockSetup b;
+    int64_t j0, nshare;
+    Spread sp;
+};
+
+__device__ __forceinline__ SpreadSetup spread_setup(const CellArgs &p, int G, double *xs, int *broken)
+{
+    SpreadSetup s;
+    const int64_t cell = blockIdx.x / G;
+    const int g = (int)(blockIdx.x - cell * G);
+    s.b = block_setup(p, cell);
+    const int64_t share = (s.b.n + G - 1) / G;
+    s.j0 = share * g < s.b.n ? share * g : s.b.n;
+    s.nshare = s.j0 + share < s.b.n ? share : s.b.n - s.j0;
+    s.sp.slots = g_sp_slots;
+    s.sp.count = g_sp_count + cell;
+    s.sp.first = cell * G;
+    s.sp.g = g;
+    s.sp.G = G;
+    s.sp.xs = xs;
+    s.sp.broken = broken;
+    if (threadIdx.x == 0) *broken = 0;
+    __syncthreads();
+    return s;
+}
+
+// get_max + get_ts (core.py:632-739, 982-994), G workgroups per cell
+__global__ __launch_bounds__(BK_THREADS) void cell_fit_spread_kernel(CellArgs p, int G, const double *guess,
+                                                                     double guess0, const double *beta,
+                                                                     double beta0, double *alpha, double *ts,
+                                                                     int32_t *flags)
+{
+    __shared__ double s_red[3 * BK_WAVES];
+    __shared__ int s_redi[BK_WAVES];
+    __shared__ double s_xs[SP_SLOT * SP_MAX_G];
+    __shared__ int s_broken;
+    const SpreadSetup s = spread_setup(p, G, s_xs, &s_broken);
+    const int64_t cell = blockIdx.x / G;
+    SpreadCell cd{p.we + s.b.lo + s.j0, s.nshare, (int)threadIdx.x, p.swap != 0, s_red, s_redi, s.sp};
+    int fl = 0;
+    double a = qnan(), t = qnan();
+    if (s.b.bad) {
+        fl = GODOT_F_FAILED;
+    } else {
+        a = fit_alpha(cd, s.b.S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
+        if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, s.b.S, a);
+    }
+    __syncthreads();
+    if (s_broken) {
+        fl |= GODOT_F_FAILED;
+        a = t = qnan();
+    }
+    if (threadIdx.x == 0 && s.sp.g == 0) {
+        alpha[cell] = a;
+        if (ts) ts[cell] = t;
+        if (flags) flags[cell] = fl;
+    }
+}
+
+// get_logpdf (core.py:851-932), G workgroups per cell.  Maximum and support
+// come from the shared schedule on the workgroup's share of the photons; the
+// grid is split by points: a workgroup takes four points at a time and runs
+// over all photons of the cell for them.
+__global__ __launch_bounds__(BK_THREADS) void cell_logpdf_spread_kernel(CellArgs p, int G,
+                                                                        const double *__restrict__ aopt_in,
+                                                                        double dlogl, int npt, int include_zero,
+                                                                        double *__restrict__ dom,
+                                                                        double *__restrict__ cod,
+                                                                        int32_t *__restrict__ flags)
+{
+    __shared__ double s_red[3 * BK_WAVES];
+    __shared__ int s_redi[BK_WAVES];
+    __shared__ double s_xs[SP_SLOT * SP_MAX_G];
+    __shared__ int s_broken;
+    const SpreadSetup s = spread_setup(p, G, s_xs, &s_broken);
+    const int tid = threadIdx.x;
+    const int64_t cell = blockIdx.x / G;
+    const bool swap = p.swap != 0;
+    SpreadCell cd{p.we + s.b.lo + s.j0, s.nshare, tid, swap, s_red, s_redi, s.sp};
+    // the whole cell, for the products of the grid (no exchange: block_prod only)
+    const BlockCell whole{p.we + s.b.lo, s.b.n, tid, swap, s_red, s_redi, {}};
+    const double *w = p.we + s.b.lo;
+    const int64_t n = s.b.n;
+    const double S = s.b.S;
+    int fl = 0;
+    bool ok = !s.b.bad;
+    double aopt = qnan();
+    if (s.b.bad) {
+        fl = GODOT_F_FAILED;
+    } else if (aopt_in) {
+        aopt = aopt_in[cell];
+    } else {
+        aopt = fit_alpha(cd, S, 1.0, 1.0, fl);
+        if (fl & GODOT_F_FAILED) ok = false;
+    }
+    bool done = !ok;
+    for (int round = 0; !done && round <= 50; ++round) {
+        const Support sp = support_search(cd, S, aopt, dlogl, include_zero != 0);
+        const double step = (npt > 1) ? (sp.amax - sp.amin) / (double)(npt - 1) : 0.0;
+        double best = -INFINITY;
+        int ibest = npt;
+        bool anynan = false;
+        for (int base = s.sp.g * BK_PPL; base < npt; base += G * BK_PPL) {
+            double av[BK_PPL], sg[BK_PPL], of[BK_PPL], pr[BK_PPL];
+            int ex[BK_PPL];
+#pragma unroll
+            for (int u = 0; u < BK_PPL; ++u) {
+                const int i = base + u < npt ? base + u : npt - 1;
+                av[u] = grid_point(sp.amin, sp.amax, step, i, npt);
+                // alpha w + (1 - w) as 1 + (alpha - 1) w; on complemented weights alpha - (alpha - 1) w
+                sg[u] = swap ? 1.0 - av[u] : av[u] - 1.0;
+                of[u] = swap ? av[u] : 1.0;
+                pr[u] = 1.0;
+                ex[u] = 0;
+            }
+            int64_t i = tid;
+            int k = 0;
+            for (; i + 3 * BK_THREADS < n; i += 4 * BK_THREADS) {
+                const double w0 = w[i], w1 = w[i + BK_THREADS], w2 = w[i + 2 * BK_THREADS],
+                             w3 = w[i + 3 * BK_THREADS];
+#pragma unroll
+                for (int u = 0; u < BK_PPL; ++u)
+                    pr[u] *= (fma(sg[u], w0, of[u]) * fma(sg[u], w1, of[u])) *
+                             (fma(sg[u], w2, of[u]) * fma(sg[u], w3, of[u]));
+                if ((++k & 1) == 0) {
+#pragma unroll
+                    for (int u = 0; u < BK_PPL; ++u) {
+                        ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                        pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BK_PPL; ++u) {
+                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+            }
+            for (; i < n; i += BK_THREADS) {     // at most three photons per thread
+                const double wi = w[i];
+#pragma unroll
+                for (int u = 0; u < BK_PPL; ++u) pr[u] *= fma(sg[u], wi, of[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BK_PPL; ++u) {
+                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+                whole.block_prod(pr[u], ex[u]);
+                const int ip = base + u;
+                if (ip < npt) {
+                    const double v = log_mant(pr[u], ex[u]) - S * av[u];
+                    if (tid == 0) {
+                        dom[cell * npt + ip] = av[u];
+                        cod[cell * npt + ip] = v - sp.llmax;
+                    }
+                    if (isnan(v)) anynan = true;
+                    if (v > best) {
+                        best = v;
+                        ibest = ip;
+                    }
+                }
+            }
+        }
+        // maximum of the grid against the likelihood at the centre (core.py:923-929)
+        {
+            const double v[3] = {best, (double)ibest, anynan ? 1.0 : 0.0};
+            cd.template gather<3>(v);
+            double gb = -INFINITY;
+            int cand = npt;
+            bool nan = false;
+            for (int j = 0; j < G; ++j) {
+                const double bj = s_xs[j];
+                const int kj = (int)s_xs[G + j];
+                if (bj > gb || (bj == gb && kj < cand)) {
+                    gb = bj;
+                    cand = kj;
+                }
+                nan = nan || (s_xs[2 * G + j] != 0.0);
+            }
+            const bool agree = nan || !(fabs(gb - sp.llmax) > 0.05);
+            if (agree) {
+                done = true;
+            } else if (round == 50) {
+                fl |= GODOT_F_FAILED;
+                ok = false;
+                done = true;
+            } else {
+                aopt = grid_point(sp.amin, sp.amax, step, cand >= npt ? 0 : cand, npt);
+                fl |= GODOT_F_RECENTRED;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_broken) {
+        fl |= GODOT_F_FAILED;
+        ok = false;
+    }
+    if (!ok) {
+        // every workgroup of the cell comes here together: after the last exchange
+        for (int i = s.sp.g * BK_THREADS + tid; i < npt; i += G * BK_THREADS) {
+            dom[cell * npt + i] = qnan();
+            cod[cell * npt + i] = qnan();
+        }
+    }
+    if (flags && tid == 0 && s.sp.g == 0) flags[cell] = fl;
+}
+
+// Launches that use the device's slots and counters run one after the other,
+// whatever streams they are on: each waits for the event the one before it
+// recorded.
+struct SpreadOrder {
+    std::mutex mu;
+    hipEvent_t last[64] = {};
+    int cus[64] = {};
+    int coop[64] = {};
+};
+SpreadOrder g_order;
+
+// workgroups per cell, or 0 when the cells stay with one workgroup each
+int spread_width(int dev, int64_t nph, int64_t ncell)
+{
+    if (dev < 0 || dev >= 64) return 0;
+    if (g_order.cus[dev] == 0) {
+        int cus = 0, coop = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
+        g_order.cus[dev] = cus > 0 ? cus : -1;
+        g_order.coop[dev] = coop;
+    }
+    if (!g_order.coop[dev] || g_order.cus[dev] <= 0) return 0;
+    int64_t width = g_order.cus[dev] / ncell;
+    const int64_t by_size = nph / ncell / SP_MIN_SHARE;
+    if (width > by_size) width = by_size;
+    if (width > SP_MAX_G) width = SP_MAX_G;
+    if (width * ncell > SP_MAX_WG) width = SP_MAX_WG / ncell;
+    return width >= 2 ? (int)width : 0;
+}
+
+// false: nothing was launched (the caller falls back to one workgroup per cell)
+bool spread_launch(const void *kernel, int64_t nph, int64_t ncell, void **args, int *width_arg, hipStream_t st)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_order.mu);
+    const int G = spread_width(dev, nph, ncell);
+    if (G == 0) return false;
+    *width_arg = G;
+    if (!g_order.last[dev] &&
+        hipEventCreateWithFlags(&g_order.last[dev], hipEventDisableTiming) != hipSuccess) {
+        g_order.last[dev] = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
+    if (hipStreamWaitEvent(st, g_order.last[dev], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hipLaunchKernelGGL(spread_reset_kernel, dim3(1), dim3(256), 0, st);
+    const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3((unsigned)(ncell * G)), dim3(BK_THREADS), args, 0, st);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    (void)hipEventRecord(g_order.last[dev], st);
+    return true;
+}
+
 }   // namespace
 
 namespace godot_detail {
@@ -465,6 +867,11 @@ void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const in
                       double beta0, int swap, double *alpha, double *ts, int32_t *flags, hipStream_t st)
 {
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    {
+        int G = 0;
+        void *args[] = {&p, &G, &guess, &guess0, &beta, &beta0, &alpha, &ts, &flags};
+        if (spread_launch((const void *)cell_fit_spread_kernel, nph, ncell, args, &G, st)) return;
+    }
     hipLaunchKernelGGL(cell_fit_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, guess, guess0,
                        beta, beta0, alpha, ts, flags);
 }
@@ -474,6 +881,11 @@ void logpdf_block_launch(const double *we, int64_t nph, const int64_t *lo, const
                          int include_zero, int swap, double *dom, double *cod, int32_t *flags, hipStream_t st)
 {
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
+    {
+        int G = 0;
+        void *args[] = {&p, &G, &aopt, &dlogl, &npt, &include_zero, &dom, &cod, &flags};
+        if (spread_launch((const void *)cell_logpdf_spread_kernel, nph, ncell, args, &G, st)) return;
+    }
     hipLaunchKernelGGL(cell_logpdf_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, we, aopt,
                        dlogl, npt, include_zero, dom, cod, flags);
 }

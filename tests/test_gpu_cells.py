@@ -361,6 +361,49 @@ def test_very_large_cells(variant):
             assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), c
 
 
+@pytest.mark.parametrize('shape', ['spread64', 'one_workgroup'])
+def test_very_large_cells_by_layout(shape):
+    """The two layouts of very large cells: few cells, each spread over many workgroups
+    that exchange partial sums (3 cells of ~600 000 photons), and more cells than half the
+    compute units, one workgroup each (150 cells of ~17 000)."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(5 + len(shape))
+    if shape == 'spread64':
+        cnt = np.array([600001, 580000, 655003], dtype=np.int64)
+        check = [0, 1, 2]
+    else:
+        cnt = rng.integers(16500, 18000, 150).astype(np.int64)
+        check = [0, 7, 77, 149]
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = cnt * 0.17 * rng.choice([0.4, 1.0, 2.5], len(cnt))
+    B = S * 5
+    wd, od = torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev)
+    cr = ops.CellRanges.from_offsets(wd, od, torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev))
+    alpha, ts, flags = ops.cell_fit(cr)
+    dom, cod, gfl = ops.cell_logpdf(cr, dlogl=20, npt=100)
+    # a second call reuses the exchange slots: same bits
+    alpha2, ts2, _ = ops.cell_fit(cr)
+    dom2, cod2, _ = ops.cell_logpdf(cr, dlogl=20, npt=100)
+    assert torch.equal(alpha, alpha2) and torch.equal(ts, ts2)
+    assert torch.equal(dom, dom2) and torch.equal(cod, cod2)
+    alpha, ts, dom, cod = alpha.cpu().numpy(), ts.cpu().numpy(), dom.cpu().numpy(), cod.cpu().numpy()
+    assert not (flags.cpu().numpy() & 0x10).any() and not (gfl.cpu().numpy() & 0x10).any()
+    with np.errstate(all='ignore'):
+        for c in check:
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            a = cl.get_max()
+            t = cl.get_ts(a)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            assert abs(alpha[c] - a) <= RTOL * max(1, abs(a)), (c, alpha[c], a)
+            assert abs(ts[c] - t) <= RTOL * max(sc, abs(t)), (c, ts[c], t)
+            d, v = cl.get_logpdf(dlogl=20, npt=100)
+            assert np.abs(dom[c] - d).max() <= RTOL * max(1.0, np.abs(d).max()), c
+            assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), c
+
+
 def test_joint_fit_meets_reference_likelihood(golden):
     """get_max(profile_background=True): the reference's optimiser (scipy TNC,
     ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
