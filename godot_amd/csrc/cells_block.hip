@@ -9,8 +9,8 @@
 // cells_common.hpp.
 //
 // When the cells are fewer than the compute units, each cell is spread over G
-// workgroups (one per compute unit, launched cooperatively so that all of them
-// are resident): a workgroup streams its share of the photons, publishes its
+// workgroups (at most one per compute unit, so that all of them are resident
+// together): a workgroup streams its share of the photons, publishes its
 // partial sums in a slot of device memory, waits for the other G - 1 at a
 // barrier of the cell's own, and adds the G partial results in a fixed order, so
 // that every workgroup of a cell holds the same bits and walks the same path
@@ -88,7 +88,7 @@ struct BlockCellT {
                 long spins = 0;
                 while (__hip_atomic_load(sp.count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > SP_SPIN_LIMIT) {   // never on a cooperative launch; ends a broken one
+                    if (++spins > SP_SPIN_LIMIT) {   // seconds: the others never came; fail the cell, do not hang
                         *sp.broken = 1;
                         break;
                     }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
 }
 
 // ---------------------------------------------------------------------------
-// Spread cells: G workgroups per cell (cooperative launch)
+// Spread cells: G workgroups per cell
 // ---------------------------------------------------------------------------
 
 struct SpreadSetup {
@@ -799,7 +799,6 @@ struct SpreadOrder {
     std::mutex mu;
     hipEvent_t last[64] = {};
     int cus[64] = {};
-    int coop[64] = {};
 };
 SpreadOrder g_order;
 
@@ -808,13 +807,11 @@ int spread_width(int dev, int64_t nph, int64_t ncell)
 {
     if (dev < 0 || dev >= 64) return 0;
     if (g_order.cus[dev] == 0) {
-        int cus = 0, coop = 0;
+        int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
-        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
         g_order.cus[dev] = cus > 0 ? cus : -1;
-        g_order.coop[dev] = coop;
     }
-    if (!g_order.coop[dev] || g_order.cus[dev] <= 0) return 0;
+    if (g_order.cus[dev] <= 0) return 0;
     int64_t width = g_order.cus[dev] / ncell;
     const int64_t by_size = nph / ncell / SP_MIN_SHARE;
     if (width > by_size) width = by_size;
@@ -843,7 +840,12 @@ bool spread_launch(const void *kernel, int64_t nph, int64_t ncell, void **args, 
         return false;
     }
     hipLaunchKernelGGL(spread_reset_kernel, dim3(1), dim3(256), 0, st);
-    const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3((unsigned)(ncell * G)), dim3(BK_THREADS), args, 0, st);
+    // An ordinary launch: ncell * G is at most the number of compute units, each of which holds
+    // such a workgroup, and no other launch that waits inside a kernel runs beside this one, so
+    // every workgroup becomes resident without any of those already waiting having to leave.
+    // (hipLaunchCooperativeKernel would state that to the runtime, but a process that has used it
+    // ends in a segmentation fault at exit under rocprofv3's kernel trace.)
+    const hipError_t e = hipLaunchKernel(kernel, dim3((unsigned)(ncell * G)), dim3(BK_THREADS), args, 0, st);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return false;
