@@ -148,30 +148,51 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
         const double x0 = xp[0], xl = xp[npt - 1];
         const double inv_step = (double)(npt - 1) / (xl - x0);
         const double step = (xl - x0) / (double)(npt - 1);
-        Best b{-INFINITY, ngrid};
         if (uniform[c]) {                       // the same for the whole workgroup
 #pragma unroll
-            for (int u = 0; u < BB_PPT; ++u) {
-                const int k = u * BB_THREADS + tid;
-                if (k < ngrid) {
-                    acc[u] += interp_one<true>(x[u], xp, fs, npt, x0, xl, inv_step, step);
-                    b = best_of(b, Best{acc[u], k});
-                }
-            }
+            for (int u = 0; u < BB_PPT; ++u)
+                acc[u] += interp_one<true>(x[u], xp, fs, npt, x0, xl, inv_step, step);
         } else {
 #pragma unroll
-            for (int u = 0; u < BB_PPT; ++u) {
-                const int k = u * BB_THREADS + tid;
-                if (k < ngrid) {
-                    acc[u] += interp_one<false>(x[u], xp, fs, npt, x0, xl, inv_step, step);
-                    b = best_of(b, Best{acc[u], k});
+            for (int u = 0; u < BB_PPT; ++u)
+                acc[u] += interp_one<false>(x[u], xp, fs, npt, x0, xl, inv_step, step);
+        }
+        // numpy.argmax over the grid: this thread's points first (ascending index, so a
+        // strict comparison keeps the first of equals; slots past the grid repeat its last
+        // point and are left out)
+        double m = acc[0];
+        int ku = 0;
+        bool nan = isnan(acc[0]);
+#pragma unroll
+        for (int u = 1; u < BB_PPT; ++u) {
+            if (u * BB_THREADS + tid < ngrid) {
+                nan = nan || isnan(acc[u]);
+                if (acc[u] > m) {
+                    m = acc[u];
+                    ku = u;
                 }
             }
         }
+        if (tid >= ngrid) m = -INFINITY;
+        Best b{m, tid < ngrid ? ku * BB_THREADS + tid : ngrid};
+        if (__ballot(nan ? 1 : 0) == 0) {
+            // no NaN in the wavefront: the maximum, then the lowest index that has it
+            const double mw = team_fmax<64>(m);
+            b.k = team_min_i32<64>(m == mw ? b.k : ngrid);
+            b.v = mw;
+        } else {
+            // a NaN counts as the maximum (its first index): the general order, lane by lane
+            b = Best{-INFINITY, ngrid};
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
-            b = best_of(b, other);
+            for (int u = 0; u < BB_PPT; ++u) {
+                const int k = u * BB_THREADS + tid;
+                if (k < ngrid) b = best_of(b, Best{acc[u], k});
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+                b = best_of(b, other);
+            }
         }
         const int slot = (int)((i - c) % BB_RING);
         if (lane == 0) {

@@ -74,6 +74,10 @@ GODOT_TEAM_REDUCE(team_sum, double, dpp_f64, __shfl_xor, GODOT_OP_ADD)
 GODOT_TEAM_REDUCE(team_prod, double, dpp_f64, __shfl_xor, GODOT_OP_MUL)
 GODOT_TEAM_REDUCE(team_max, double, dpp_f64, __shfl_xor, GODOT_OP_MAX)
 GODOT_TEAM_REDUCE(team_sum_i32, int, dpp_i32, __shfl_xor, GODOT_OP_ADD)
+#define GODOT_OP_FMAX(a, b) fmax((a), (b))
+#define GODOT_OP_IMIN(a, b) (((b) < (a)) ? (b) : (a))
+GODOT_TEAM_REDUCE(team_fmax, double, dpp_f64, __shfl_xor, GODOT_OP_FMAX)    // ignores NaN
+GODOT_TEAM_REDUCE(team_min_i32, int, dpp_i32, __shfl_xor, GODOT_OP_IMIN)
 
 // 1/d for finite d away from 0 and from the ends of the exponent range:
 // hardware estimate + two Newton steps (about 1 ulp).  No scaling, no
