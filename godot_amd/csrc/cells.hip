@@ -100,7 +100,7 @@ __device__ __forceinline__ void cell_fit_body(const CellArgs &p, const double *g
             if (lane == 0) {
                 alpha[cell] = a;
                 if (ts) ts[cell] = t;
-                if (flags) flags[cell] = fl;
+                if (flags) flags[cell] = fit_flags(fl, a);
             }
         }
     }

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_block_kernel(CellArgs p, 
     if (threadIdx.x == 0) {
         alpha[cell] = a;
         if (ts) ts[cell] = t;
-        if (flags) flags[cell] = fl;
+        if (flags) flags[cell] = fit_flags(fl, a);
     }
 }
 
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_spread_kernel(CellArgs p,
     if (threadIdx.x == 0 && s.sp.g == 0) {
         alpha[cell] = a;
         if (ts) ts[cell] = t;
-        if (flags) flags[cell] = fl;
+        if (flags) flags[cell] = fit_flags(fl, a);
     }
 }
 

@@ -423,6 +423,13 @@ template <class CD, bool B0, bool CHECK0 = true, bool WANT_L0 = false>
 __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, double &a_out, bool &at_zero,
                                  LogProd *l0 = nullptr);
 
+// The flags a fitted cell leaves with: a maximum at the boundary is marked whichever way
+// the schedule got there (the sign of the derivative at zero, or an iterate clamped to it).
+__device__ __forceinline__ int fit_flags(int fl, double alpha)
+{
+    return alpha == 0.0 ? (fl | GODOT_F_AT_ZERO) : fl;
+}
+
 // One pass of the fixed schedule (core.py:639-680) from the zero-based start
 // values g = guess - 1, b = beta - 1.  Returns true when the result `a` (zero-
 // based) is final, false when the reference would call itself again with

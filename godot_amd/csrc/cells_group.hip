@@ -476,7 +476,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
                 if (tl == 0) {
                     alpha[c] = isnan(a) ? qnan() : a;
                     if (ts) ts[c] = t;
-                    if (flags) flags[c] = fl;
+                    if (flags) flags[c] = fit_flags(fl, a);
                 }
             }
         }
@@ -498,7 +498,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         if (o_full || o_hand) alpha[c] = o_a;
         if (o_full) {
             if (ts) ts[c] = o_t;
-            if (flags) flags[c] = o_fl;
+            if (flags) flags[c] = fit_flags(o_fl, o_a);
         }
     }
 
@@ -522,7 +522,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         if (lane == 0) {
             alpha[c] = a_s;
             if (ts) ts[c] = t_s;
-            if (flags) flags[c] = fl_s;
+            if (flags) flags[c] = fit_flags(fl_s, a_s);
         }
     }
 }
@@ -606,7 +606,7 @@ __device__ __forceinline__ void cell_fit_restart_body(const CellArgs &p, const d
             if (q == 0) {
                 alpha[c] = isnan(a) ? qnan() : a;
                 if (ts) ts[c] = t;
-                if (flags) flags[c] = depth << 1;
+                if (flags) flags[c] = fit_flags(depth << 1, a);
             }
         }
         // the bracketing fallback: all 64 lanes on one cell, out of line
@@ -623,7 +623,7 @@ __device__ __forceinline__ void cell_fit_restart_body(const CellArgs &p, const d
             if (lane == 0) {
                 alpha[c_s] = a_s;
                 if (ts) ts[c_s] = t_s;
-                if (flags) flags[c_s] = fl_s;
+                if (flags) flags[c_s] = fit_flags(fl_s, a_s);
             }
         }
     }

@@ -39,7 +39,7 @@ extern "C" {
 #define GODOT_E_UNSUPPORTED -4  /* size outside what the kernels accept */
 
 /* per-cell status bits written to `flags` outputs */
-#define GODOT_F_AT_ZERO     0x01  /* maximum at the alpha = 0 boundary         */
+#define GODOT_F_AT_ZERO     0x01  /* alpha-hat is exactly 0 (boundary maximum)  */
 #define GODOT_F_DEPTH_MASK  0x06  /* restart depth (0..3) << 1                 */
 #define GODOT_F_BRENT       0x08  /* bracketing root finder was used           */
 #define GODOT_F_FAILED      0x10  /* no bracket / no convergence: output NaN   */

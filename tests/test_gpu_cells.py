@@ -361,6 +361,40 @@ def test_very_large_cells(variant):
             assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), c
 
 
+def test_zero_alpha_is_flagged_however_it_was_reached():
+    """alpha-hat = 0 comes about in two ways: the derivative at zero is negative, or a
+    Newton/Halley iterate is clamped to the boundary (core.py:671, 680).  Both carry the
+    at-zero flag, and both agree with the oracle.  Heavy-tailed cell sizes with a strong
+    source term produce hundreds of each."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(12)
+    ncell = 10000
+    cnt = (rng.geometric(1.0 / 61, ncell) - 1).astype(np.int64)
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    n = int(off[-1])
+    we = np.clip(np.where(rng.random(n) < 0.5, rng.beta(0.3, 1.5, n), rng.beta(5, 0.5, n)), 1e-7, 1 - 1e-7)
+    S = 60 * we.mean() * 3 * rng.uniform(0.7, 1.3, ncell)
+    B = 60 * (1 - we.mean()) * rng.uniform(0.7, 1.3, ncell)
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev))
+    alpha, ts, flags = ops.cell_fit(cr)
+    alpha, ts, flags = alpha.cpu().numpy(), ts.cpu().numpy(), flags.cpu().numpy()
+    assert np.array_equal((flags & 0x01) != 0, alpha == 0)
+    assert not (flags & 0x10).any()
+    clamped = 0
+    with np.errstate(all='ignore'):
+        for c in range(ncell):
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            a = cl.get_max()
+            assert abs(alpha[c] - a) <= RTOL * max(1, abs(a)), (c, alpha[c], a)
+            assert (a == 0) == (alpha[c] == 0), c
+            if a == 0 and len(w) and (w / (1 - w)).sum() - S[c] >= 0:
+                clamped += 1        # the derivative at zero did not send it there
+    assert (alpha == 0).sum() > 300 and clamped > 10
+
+
 @pytest.mark.parametrize('shape', ['spread64', 'one_workgroup'])
 def test_very_large_cells_by_layout(shape):
     """The two layouts of very large cells: few cells, each spread over many workgroups
