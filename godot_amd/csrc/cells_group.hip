@@ -855,12 +855,16 @@ __global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, co
             }
             // agreement of the grid maximum with the likelihood at the centre (core.py:923-929);
             // numpy's argmax returns the first NaN if there is one, and the reference's
-            // comparison is then false: the grid is accepted
-            const double gbest = team_max<64>(best);
+            // comparison is then false: the grid is accepted.
             const bool nan_c = __any(anynan ? 1 : 0);
-            const bool agree = nan_c || !(fabs(gbest - ll_c) > 0.05);
+            // Rounding is monotone, so |max - llmax| > 0.05 is decided lane by lane: some
+            // lane's best lies more than 0.05 above, or every lane's more than 0.05 below.
+            const double dbest = best - ll_c;
+            const bool far = __any(dbest > 0.05 ? 1 : 0) || __all(dbest < -0.05 ? 1 : 0);   // false on NaN
+            const bool agree = nan_c || !far;
             int inew = 0;
             if (!agree) {
+                const double gbest = team_max<64>(best);
                 int cand = (best == gbest) ? ibest : npt;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
