@@ -438,6 +438,42 @@ def test_very_large_cells_by_layout(shape):
             assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), c
 
 
+def test_spread_cells_on_two_streams_do_not_interleave():
+    """Spread cells exchange partial sums through one device array of the library; launches
+    on different streams are chained by the library, so calls issued from two streams at
+    once give the bits of calls issued one after the other."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    sets = []
+    for k in range(2):
+        cnt = np.array([300001, 250000 + 17 * k, 410003], dtype=np.int64)
+        off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+        we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+        S = cnt * 0.17 * np.array([0.5, 1.0, 2.0])
+        sets.append(ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                                torch.from_numpy(S).to(dev), torch.from_numpy(S * 5).to(dev)))
+    serial = []
+    for cr in sets:
+        a, t, f = ops.cell_fit(cr)
+        d, c, g = ops.cell_logpdf(cr, dlogl=20, npt=100)
+        serial.append((a, t, d, c))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in sets]
+    for rep in range(3):
+        got = []
+        for cr, st in zip(sets, streams):
+            with torch.cuda.stream(st):
+                a, t, f = ops.cell_fit(cr)
+                d, c, g = ops.cell_logpdf(cr, dlogl=20, npt=100)
+                got.append((a, t, d, c, f, g))
+        torch.cuda.synchronize()
+        for want, have in zip(serial, got):
+            for w, h in zip(want, have[:4]):
+                assert torch.equal(w, h)
+            assert not (have[4].cpu().numpy() & 0x10).any() and not (have[5].cpu().numpy() & 0x10).any()
+
+
 def test_joint_fit_meets_reference_likelihood(golden):
     """get_max(profile_background=True): the reference's optimiser (scipy TNC,
     ftol 1e-3) defines (alpha, beta) only to its tolerance, so the contract is
