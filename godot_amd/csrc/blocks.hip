@@ -48,19 +48,30 @@ __device__ __forceinline__ double linspace_at(double a0, double a1, double step,
     return (double)i * step + a0;
 }
 
-// uniform[c] = 1 when the abscissae of cell c are, to the bit, numpy.linspace of their
-// end points (what get_logpdf produces): the fitness kernel then computes them instead
-// of loading them
-__global__ void bb_uniform_kernel(const double *__restrict__ dom, int64_t ncell, int npt, int32_t *uniform)
+// Per-cell facts the fitness kernel branches on:
+//   BB_UNIFORM  the abscissae of cell c are, to the bit, numpy.linspace of their end points
+//               (what get_logpdf produces): they are computed instead of loaded;
+//   BB_CLEAN    no NaN among the abscissae, no NaN and no +inf among the values: adding the
+//               cell's interpolated profile to -inf leaves -inf, so a grid point that has
+//               fallen out of some cell's support needs no further interpolation.
+// *unclean counts the cells without BB_CLEAN (zeroed by the caller).
+constexpr int BB_UNIFORM = 1, BB_CLEAN = 2;
+
+__global__ void bb_uniform_kernel(const double *__restrict__ dom, const double *__restrict__ cod, int64_t ncell,
+                                  int npt, int32_t *facts, int32_t *unclean)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
-    const double *xp = dom + c * npt;
+    const double *xp = dom + c * npt, *fp = cod + c * npt;
     const double x0 = xp[0], xl = xp[npt - 1];
     const double step = (xl - x0) / (double)(npt - 1);
-    int ok = 1;
-    for (int j = 0; j < npt; ++j) ok &= (xp[j] == linspace_at(x0, xl, step, j, npt)) ? 1 : 0;
-    uniform[c] = ok;
+    bool uni = true, clean = true;
+    for (int j = 0; j < npt; ++j) {
+        uni = uni && (xp[j] == linspace_at(x0, xl, step, j, npt));
+        clean = clean && !isnan(xp[j]) && (fp[j] < INFINITY);      // false for NaN and +inf
+    }
+    facts[c] = (uni ? BB_UNIFORM : 0) | (clean ? BB_CLEAN : 0);
+    if (!clean) atomicAdd(unclean, 1);
 }
 
 // numpy.interp(x, xp, fp, left=-inf, right=-inf) for one x; xp is a uniform
@@ -121,7 +132,8 @@ __device__ __forceinline__ Best best_of(Best a, Best b)
 // there) of the summed profiles of cells j .. i  (core.py:1108-1136 with i0 = 0, i1 = i + 1).
 __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__restrict__ dom,
                                                                 const double2 *__restrict__ pairs,
-                                                                const int32_t *__restrict__ uniform,
+                                                                const int32_t *__restrict__ facts,
+                                                                const int32_t *__restrict__ unclean,
                                                                 int64_t ncell, int npt, int ngrid,
                                                                 int64_t row_begin, int64_t row_end,
                                                                 double *__restrict__ fit_val,
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
         acc[u] = 0.0;
     }
     const int64_t obase = i * (i + 1) / 2 - row_begin * (row_begin + 1) / 2;
+    const bool all_clean = *unclean == 0;
     int pending = 0;
     for (int64_t c = i; c >= 0; --c) {
         const double *xp = dom + c * npt;
@@ -148,14 +161,18 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
         const double x0 = xp[0], xl = xp[npt - 1];
         const double inv_step = (double)(npt - 1) / (xl - x0);
         const double step = (xl - x0) / (double)(npt - 1);
-        if (uniform[c]) {                       // the same for the whole workgroup
+        const int fc = facts[c];                // the same for the whole workgroup
+        const bool clean = (fc & BB_CLEAN) != 0;
+        if (fc & BB_UNIFORM) {
 #pragma unroll
             for (int u = 0; u < BB_PPT; ++u)
-                acc[u] += interp_one<true>(x[u], xp, fs, npt, x0, xl, inv_step, step);
+                if (!(clean && acc[u] == -INFINITY))
+                    acc[u] += interp_one<true>(x[u], xp, fs, npt, x0, xl, inv_step, step);
         } else {
 #pragma unroll
             for (int u = 0; u < BB_PPT; ++u)
-                acc[u] += interp_one<false>(x[u], xp, fs, npt, x0, xl, inv_step, step);
+                if (!(clean && acc[u] == -INFINITY))
+                    acc[u] += interp_one<false>(x[u], xp, fs, npt, x0, xl, inv_step, step);
         }
         // numpy.argmax over the grid: this thread's points first (ascending index, so a
         // strict comparison keeps the first of equals; slots past the grid repeat its last
@@ -212,8 +229,22 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
                 fit_val[obase + cc] = r.v * 2;
                 fit_arg[obase + cc] = linspace_at(a0, a1, gstep, kk, ngrid) * 2;
             }
+            // Every grid point at -inf after cell c (its maximum over the grid is -inf, in
+            // all four wavefronts) and nothing but clean cells anywhere: all longer blocks
+            // have fitness -inf at the first grid point, as numpy.argmax of all -inf gives.
+            bool dead = all_clean;
+#pragma unroll
+            for (int w = 0; w < BB_THREADS / 64; ++w) dead = dead && (s_v[slot][w] == -INFINITY);
             __syncthreads();
             pending = 0;
+            if (dead) {
+                const double arg0 = linspace_at(a0, a1, gstep, 0, ngrid) * 2;
+                for (int64_t cc = tid; cc < c; cc += BB_THREADS) {
+                    fit_val[obase + cc] = -INFINITY;
+                    fit_arg[obase + cc] = arg0;
+                }
+                return;
+            }
         }
     }
 }
@@ -332,8 +363,8 @@ __global__ __launch_bounds__(1024) void bb_within_kernel(const double *__restric
 extern "C" size_t godot_bb_workspace_bytes(int64_t ncell, int npt)
 {
     if (ncell < 0 || npt < 0) return 0;
-    // (value, slope) pairs, then one flag per cell
-    return (size_t)ncell * (size_t)npt * sizeof(double2) + (size_t)ncell * sizeof(int32_t);
+    // (value, slope) pairs, then one word of facts per cell and the count of unclean cells
+    return (size_t)ncell * (size_t)npt * sizeof(double2) + ((size_t)ncell + 1) * sizeof(int32_t);
 }
 
 extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int npt, int ngrid,
@@ -354,12 +385,15 @@ extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t nc
     double2 *pairs = (double2 *)workspace;
     hipLaunchKernelGGL(bb_slopes_kernel, dim3((unsigned)ceil_div(ncell * npt, 256)), dim3(256), 0, st, dom, cod,
                        ncell, npt, pairs);
-    int32_t *uniform = (int32_t *)(pairs + (size_t)ncell * (size_t)npt);
-    hipLaunchKernelGGL(bb_uniform_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, dom, ncell, npt,
-                       uniform);
+    int32_t *facts = (int32_t *)(pairs + (size_t)ncell * (size_t)npt);
+    int32_t *unclean = facts + ncell;
+    GODOT_REQUIRE(hipMemsetAsync(unclean, 0, sizeof(int32_t), st) == hipSuccess, GODOT_E_LAUNCH,
+                  "godot_bb_fitness: clearing the workspace failed");
+    hipLaunchKernelGGL(bb_uniform_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0, st, dom, cod, ncell,
+                       npt, facts, unclean);
     hipLaunchKernelGGL(bb_fitness_kernel, dim3((unsigned)(row_end - row_begin)), dim3(BB_THREADS), 0, st, dom,
-                       (const double2 *)pairs, (const int32_t *)uniform, ncell, npt, ngrid, row_begin, row_end,
-                       fit_val, fit_arg);
+                       (const double2 *)pairs, (const int32_t *)facts, (const int32_t *)unclean, ncell, npt, ngrid,
+                       row_begin, row_end, fit_val, fit_arg);
     GODOT_LAUNCH_CHECK("godot_bb_fitness");
     return GODOT_OK;
 }

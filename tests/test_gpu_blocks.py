@@ -143,6 +143,34 @@ def test_fitness_matches_oracle_on_random_profiles():
         assert np.isnan(fv[~clean]).all()
 
 
+@pytest.mark.parametrize('poison', [None, 'plus_inf'])
+def test_fitness_with_disjoint_supports(poison):
+    """A flaring source: runs of cells whose supports do not overlap.  Grid points that left
+    some cell's support stay at -inf and whole rows end early; a +inf among the values makes
+    -inf + inf = NaN in numpy and must switch both shortcuts off for what it touches."""
+    from godot_amd import ops
+    rng = np.random.default_rng(3)
+    n, npt = 180, 50
+    state = (np.arange(n) // 37) % 2                    # quiet, flare, quiet, ...
+    lo = np.where(state == 0, rng.uniform(0.0, 0.3, n), rng.uniform(4.0, 4.5, n))
+    hi = lo + np.where(state == 0, rng.uniform(0.8, 1.5, n), rng.uniform(2.0, 3.0, n))
+    dom = np.linspace(lo, hi, npt).T.copy()
+    peak = rng.uniform(lo, hi)
+    cod = -((dom - peak[:, None]) * rng.uniform(1, 6, n)[:, None]) ** 2
+    cod -= cod.max(axis=1, keepdims=True)
+    if poison == 'plus_inf':
+        cod[60, 10] = np.inf
+    with np.errstate(all='ignore'):
+        ref = [orc.bb_fitness(dom, cod, 0, i + 1) for i in range(n)]
+    fv, fa = ops.bb_fitness(_d(dom), _d(cod))
+    fv, fa = fv.cpu().numpy(), fa.cpu().numpy()
+    rv = np.concatenate([r[0] for r in ref])
+    ra = np.concatenate([r[1] for r in ref])
+    assert np.isneginf(rv).mean() > 0.3                 # the shortcuts have something to do
+    assert np.array_equal(fv, rv, equal_nan=True)
+    assert np.array_equal(fa, ra, equal_nan=True)
+
+
 def test_fitness_row_ranges_tile_the_triangle(golden):
     """Rows computed in ranges (the multi-GPU split) concatenate to the whole."""
     from godot_amd import ops, dist as gd
