@@ -11,7 +11,11 @@
  * Conventions
  *   - Every pointer is a DEVICE pointer unless its name ends in _host.
  *   - The caller allocates every input, output and workspace; the library
- *     never allocates, frees or keeps a pointer past the call.
+ *     never allocates, frees or keeps a pointer past the call.  (Its only
+ *     device memory of its own is a 34 KB file-scope array per GPU, through
+ *     which godot_cell_fit / godot_cell_logpdf let the workgroups of one very
+ *     large cell exchange partial sums; launches that use it are ordered by
+ *     the library across streams and cannot be captured into a HIP graph.)
  *   - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream) and is asynchronous with respect to the host.
  *   - Return value: 0 on success, a negative GODOT_E_* code on failure;
