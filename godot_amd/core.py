@@ -587,11 +587,32 @@ class CellLogLikelihood(object):
         return ((W - self.S) * t2 + (N - self.B - W) * t1) / (W2 * t2 - t1 ** 2)
 
 
+def _raise_as_reference(flags, allow):
+    """The reference fits cell after cell and stops at the first one it cannot fit: a
+    ValueError from its root finder when the score has no sign change (core.py:728-739),
+    a RecursionError when get_logpdf re-centres without end (core.py:923-929).  The
+    kernels mark such cells (GODOT_F_FAILED) and go on; with allow=False the batch call
+    then raises what the reference would have."""
+    if allow:
+        return
+    bad = (flags & 0x10) != 0
+    if bool(bad.any().cpu()):
+        fl = int(flags[bad][0].cpu())
+        if fl & 0x08:
+            raise ValueError('f(a) and f(b) must have different signs')
+        raise RecursionError('the profile of a cell was re-centred 50 times without agreeing with its maximum')
+
+
 class CellsLogLikelihood(object):
     """Batch driver: cached (ncell, 200) log-likelihood profiles, fluxes and
-    the raw light curve (reference core.py:1070-1098, 1227-1336)."""
+    the raw light curve (reference core.py:1070-1098, 1227-1336).
 
-    def __init__(self, cells, profile_background=False, swap=False, reverse=False, device=None):
+    allow_failed_cells=True keeps going where the reference raises out of a cell it
+    cannot fit: such cells get NaN profiles, fluxes and light-curve rows."""
+
+    def __init__(self, cells, profile_background=False, swap=False, reverse=False, device=None,
+                 allow_failed_cells=False):
+        self.allow_failed_cells = bool(allow_failed_cells)
         batch = _as_batch(cells, device=device)
         if reverse:
             batch = batch[::-1] if not isinstance(batch, CellBatch) else CellBatch(
@@ -611,6 +632,7 @@ class CellsLogLikelihood(object):
         else:
             self._dom_d, self._cod_d, self._flags = ops.cell_logpdf(self._cr, dlogl=30, npt=200,
                                                                     swap=self._swap)
+            _raise_as_reference(self._flags, self.allow_failed_cells)
         self._dom_h = self._cod_h = None
         self.fitness_vals = None
 
@@ -658,7 +680,8 @@ class CellsLogLikelihood(object):
             ts = 2 * (lp1 - lp0)
             ts = torch.where((aopt == 0) | (self._cr.S == 0), torch.zeros_like(ts), ts)
             return aopt, ts, xlo, xhi
-        aopt, ts, _ = ops.cell_fit(self._cr, guess=ag, beta=1.0, swap=self._swap)
+        aopt, ts, fl = ops.cell_fit(self._cr, guess=ag, beta=1.0, swap=self._swap)
+        _raise_as_reference(fl, self.allow_failed_cells)
         return aopt, ts, xlo, xhi
 
     def get_flux(self, idx, conf=[0.05, 0.95]):
@@ -671,6 +694,7 @@ class CellsLogLikelihood(object):
         sub._cod_d = self._cod_d[idx:idx + 1].contiguous()
         sub._swap = self._swap
         sub.profile_background = self.profile_background
+        sub.allow_failed_cells = self.allow_failed_cells
         aopt, ts, xlo, xhi = sub.get_flux_all(conf)
         return _scalar(aopt), _scalar(ts), np.array([_scalar(xlo), _scalar(xhi)])
 

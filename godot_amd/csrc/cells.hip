@@ -581,6 +581,12 @@ __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop
     double a = alpha[c], t = ts[c];
     double *r = rows + c * 5;
     r[0] = terr;
+    if (isnan(a) || isnan(xhi[c])) {
+        // a cell that could not be fitted or profiled (the reference stops with an exception
+        // there): no number in its row
+        r[1] = r[2] = r[3] = r[4] = a + xhi[c];
+        return;
+    }
     if (t <= tsmin) {
         r[1] = xhi[c];
         r[2] = 0;

@@ -495,7 +495,11 @@ __global__ void bluestein_post_kernel(const cplx *Y, int64_t L, int64_t M, int64
     cplx y = Y[k];
     double inv = 1.0 / (double)M;
     cplx conv{y.x * inv, -y.y * inv};
-    X[k] = cmul(chirp(k, L, -1.0), conv);
+    cplx x = cmul(chirp(k, L, -1.0), conv);
+    // the series is real: the zero-frequency and Nyquist bins are real, exactly (as numpy's
+    // rfft returns them), not merely to rounding
+    if (k == 0 || 2 * k == L) x.y = 0.0;
+    X[k] = x;
 }
 
 inline int64_t bluestein_M(int64_t L)

@@ -438,6 +438,42 @@ def test_very_large_cells_by_layout(shape):
             assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), c
 
 
+def test_cells_the_reference_cannot_fit_raise_the_same_error(golden):
+    """Cells at the edge of an exposure gap (hundreds of photons against an expected 0.1):
+    alpha-hat lies beyond the bracket of the reference's root finder and get_max raises
+    ValueError (core.py:728-739).  The kernels flag such a cell and give NaN; the batch
+    class raises what the reference raises, or goes on when asked to.  Fixture: cells the
+    oracle found in a randomised light curve (tools/make_golden_unfittable.py)."""
+    from godot_amd import core, ops
+    dev = _dev()
+    g = golden('unfittable_cells.npz')
+    ws = [g['we%d' % k] for k in range(int(g['n']))]
+    # two ordinary cells around them
+    rng = np.random.default_rng(0)
+    ws = [np.clip(rng.beta(0.3, 1.5, 40), 1e-6, 1 - 1e-6)] + ws + [np.clip(rng.beta(0.3, 1.5, 25), 1e-6, 1 - 1e-6)]
+    S = np.array([7.0] + [float(g['S%d' % k]) for k in range(int(g['n']))] + [4.0])
+    B = np.array([33.0] + [float(g['B%d' % k]) for k in range(int(g['n']))] + [21.0])
+    off = np.append(0, np.cumsum([len(w) for w in ws])).astype(np.int64)
+    we = np.concatenate(ws)
+    for k in range(1, len(ws) - 1):
+        with pytest.raises(ValueError), np.errstate(all='ignore'):
+            orc.CellLike(ws[k], S[k], S[k] / B[k]).get_max()
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev))
+    alpha, ts, flags = ops.cell_fit(cr)
+    alpha, flags = alpha.cpu().numpy(), flags.cpu().numpy()
+    assert np.isnan(alpha[1:-1]).all() and np.isfinite(alpha[[0, -1]]).all()
+    assert ((flags[1:-1] & 0x18) == 0x18).all() and not (flags[[0, -1]] & 0x10).any()
+    starts = np.arange(len(ws)) * 100.0
+    batch = core.CellBatch(cr.we, cr.we, cr.lo, cr.hi, torch.from_numpy(starts).to(dev),
+                           torch.from_numpy(starts + 100.0).to(dev), cr.S, cr.B)
+    with pytest.raises(ValueError, match='different signs'):
+        core.CellsLogLikelihood(batch)
+    cll = core.CellsLogLikelihood(batch, allow_failed_cells=True)
+    lc = cll.get_raw_lightcurve()
+    assert np.isnan(lc[1:-1, 2:]).all() and np.isfinite(lc[[0, -1]]).all()
+
+
 def test_spread_cells_on_two_streams_do_not_interleave():
     """Spread cells exchange partial sums through one device array of the library; launches
     on different streams are chained by the library, so calls issued from two streams at

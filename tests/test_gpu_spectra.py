@@ -38,6 +38,11 @@ def test_rfft_matches_numpy(l, n):
     assert np.abs(out[:, 0] - ref.real).max() <= tol and np.abs(out[:, 1] - ref.imag).max() <= tol
     # in practice far tighter
     assert np.abs(out[:, 0] + 1j * out[:, 1] - ref).max() <= 1e-13 * np.abs(ref).max() * np.log2(l)
+    # a real series: zero-frequency and Nyquist bins are real exactly, as numpy returns them
+    # (the reference divides the sine amplitude of bin 0 by 1 and expects 0, core.py:2690-2700)
+    assert out[0, 1] == 0.0
+    if l % 2 == 0:
+        assert out[l // 2, 1] == 0.0
 
 
 def test_rfft_linearity_and_impulse():
