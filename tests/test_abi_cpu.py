@@ -135,3 +135,27 @@ def test_cell_timeseries_file_format_is_the_references(tmp_path):
     assert back.timesys == 'topocentric' and back.alt_starts is None
     with pytest.raises(Exception):
         back.get_bary_bins()
+
+
+def test_every_entry_point_rejects_null_pointers_without_a_gpu():
+    """All error-returning entry points, called with null pointers and sizes 0, 1, -1 and 5:
+    none crashes or reaches a kernel launch; a positive size with null pointers is an error,
+    size 0 is either nothing to do (0) or an error."""
+    import ctypes
+    from godot_amd import _lib
+    ncalls = 0
+    for name, (rt, args) in _lib.SIGNATURES.items():
+        if rt is not _lib.c_int or name == 'godot_version':
+            continue
+        fn = getattr(_lib.lib, name)
+        for fill in (0, 1, -1, 5):
+            call = [None if a is ctypes.c_void_p else (float(max(fill, 0)) if a is ctypes.c_double else fill)
+                    for a in args]
+            rc = fn(*call)
+            ncalls += 1
+            assert rc <= 0, (name, fill, rc)
+            if rc:
+                assert _lib.last_error(), (name, fill)
+            if fill == 1:
+                assert rc < 0, (name, 'accepted null pointers for one element')
+    assert ncalls >= 120
