@@ -120,7 +120,31 @@ __device__ __noinline__ void fit_joint(const StreamCell<T> &cd, double S, double
         L = Ln;
         if (small) break;
     }
-    if (it >= 100) flags |= GODOT_F_FAILED;
+    if (it >= 100) {
+        // No convergence: the curvature is (nearly) singular -- one photon, or equal weights --
+        // and the maximum sits on an edge, where Newton steps along the flat direction crawl.
+        // logL is concave, so an edge point that meets the Kuhn-Tucker conditions IS the
+        // maximum, and on an edge it has a closed form: beta = 0 gives alpha = n / S, alpha = 0
+        // gives beta = n / B.
+        double e[2];
+        cd.template sums<2>([](double w, double (&s)[2]) {
+            const double iw = 1.0 - w;
+            s[0] += iw / w;
+            s[1] += w / iw;
+        }, e);
+        const double a_edge = (double)cd.n / S, b_edge = (double)cd.n / B;
+        if (e[0] / a_edge - B <= 0) {            // d logL / d beta at (n / S, 0)
+            al = a_edge;
+            be = 0.0;
+            L = full_loglike(cd, S, B, al, be);
+        } else if (e[1] / b_edge - S <= 0) {     // d logL / d alpha at (0, n / B)
+            al = 0.0;
+            be = b_edge;
+            L = full_loglike(cd, S, B, al, be);
+        } else {
+            flags |= GODOT_F_FAILED;
+        }
+    }
     alpha = al;
     beta = be;
     logl = L;

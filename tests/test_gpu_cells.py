@@ -535,6 +535,46 @@ def test_joint_fit_meets_reference_likelihood(golden):
     assert np.abs(a - g['joint_ab'][:, 0]).max() < 0.2
 
 
+def test_joint_fit_with_singular_curvature_ends_on_the_edge():
+    """One photon, or all weights equal: the Hessian of logL in (alpha, beta)
+    has rank one and the maximum is on an edge (alpha = n/S, beta = 0 or
+    alpha = 0, beta = n/B).  The cells are fitted, not flagged: the point
+    returned meets the Kuhn-Tucker conditions and its logL is the reference's
+    (get_max(profile_background=True), core.py:552-630) within its ftol."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    cells = []
+    for n in (1, 1, 1, 2, 5, 40):
+        for w0 in (0.03, 0.5, 0.97):
+            for s in (0.4, 3.0):
+                cells.append((np.full(n, w0), s * n * w0, n * (1 - w0) / s))
+    for _ in range(20):                       # one photon, arbitrary exposures
+        cells.append((rng.uniform(0.01, 0.99, 1), rng.uniform(0.05, 5), rng.uniform(0.05, 5)))
+    we = np.concatenate([c[0] for c in cells])
+    off = np.append(0, np.cumsum([len(c[0]) for c in cells])).astype(np.int64)
+    S = np.array([c[1] for c in cells])
+    B = np.array([c[2] for c in cells])
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev))
+    a, b, L, fl = [x.cpu().numpy() for x in ops.cell_fit_joint(cr)]
+    assert not (fl & 0x10).any(), np.flatnonzero(fl & 0x10)
+    assert (a >= 0).all() and (b >= 0).all()
+    with np.errstate(all='ignore'):
+        for i in range(len(cells)):
+            cl = orc.CellLike(we[off[i]:off[i + 1]], S[i], S[i] / B[i])
+            _, (nga, ngb) = cl.neg_logl_grad(a[i], b[i])
+            sc = max(1.0, cl.S, cl.B)
+            assert (abs(nga) <= 1e-7 * sc) or (a[i] == 0 and nga >= 0), (i, a[i], b[i], nga)
+            assert (abs(ngb) <= 1e-7 * sc) or (b[i] == 0 and ngb >= 0), (i, a[i], b[i], ngb)
+            assert abs(L[i] - cl.log_full_likelihood(a[i], b[i])) <= 1e-9 * max(1, abs(L[i]))
+            try:
+                ra, rb = cl.get_max_profile()
+            except Exception:
+                continue
+            assert L[i] >= cl.log_full_likelihood(ra, rb) - 2e-3, (i, a[i], b[i], ra, rb)
+
+
 def test_profile_background_grid_matches_reference(golden):
     """_get_logpdf_profile centred on a given aopt has no third-party
     optimiser inside (Brent restated): 1e-9 parity."""
