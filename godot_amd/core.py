@@ -816,6 +816,9 @@ class CellsLogLikelihood(object):
         aopt, ts, xlo, xhi = self.get_flux_all(conf=[0.159, 0.841])
         rows = ops.lightcurve_rows(self.cells.starts, self.cells.stops, aopt, ts, xlo, xhi,
                                    self._cr.S, tsmin)
+        if self.allow_failed_cells:
+            # cells the reference would have stopped at: no number in their rows
+            rows[(self._flags & 0x10) != 0] = float('nan')
         out = np.empty([len(self.cells), 6])
         out[:, 1:] = _np(rows)
         tmid = _np(0.5 * (self.cells.starts + self.cells.stops))

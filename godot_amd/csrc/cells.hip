@@ -581,12 +581,15 @@ __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop
     double a = alpha[c], t = ts[c];
     double *r = rows + c * 5;
     r[0] = terr;
-    if (isnan(a) || isnan(xhi[c])) {
-        // a cell that could not be fitted or profiled (the reference stops with an exception
-        // there): no number in its row
-        r[1] = r[2] = r[3] = r[4] = a + xhi[c];
+    if (isnan(a)) {
+        // a cell that could not be fitted (the reference stops with an exception there): no
+        // number in its row
+        r[1] = r[2] = r[3] = r[4] = a;
         return;
     }
+    // A profile that holds only NaN does not stop the reference (the search for the upper end
+    // of the support of a cell with alpha-hat = 0 can leave the domain of the logarithm,
+    // core.py:869-880): the quantiles are NaN and take their places in the row like numbers.
     if (t <= tsmin) {
         r[1] = xhi[c];
         r[2] = 0;

@@ -474,6 +474,36 @@ def test_cells_the_reference_cannot_fit_raise_the_same_error(golden):
     assert np.isnan(lc[1:-1, 2:]).all() and np.isfinite(lc[[0, -1]]).all()
 
 
+def test_profile_of_only_nan_takes_its_place_in_the_light_curve(golden):
+    """A cell with alpha-hat = 0 whose search for the upper end of the support leaves the
+    domain of the logarithm (core.py:869-880): the reference does not stop, its profile is
+    NaN throughout, and get_raw_lightcurve (core.py:1295-1336) writes the row of an upper
+    limit with NaN for the limit: [.., nan, 0, -1, 0].  Fixture: such a cell and its two
+    neighbours from a randomised light curve (tools/make_golden_nan_profile.py)."""
+    from godot_amd import core, ops
+    dev = _dev()
+    g = golden('nan_profile_cell.npz')
+    off = np.append(0, np.cumsum(g['counts'])).astype(np.int64)
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(g['we']).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(g['S']).to(dev), torch.from_numpy(g['B']).to(dev))
+    batch = core.CellBatch(cr.we, cr.we, cr.lo, cr.hi, torch.from_numpy(g['starts']).to(dev),
+                           torch.from_numpy(g['stops']).to(dev), cr.S, cr.B)
+    assert np.isnan(g['dom'][1]).all() and np.isfinite(g['dom'][[0, 2]]).all()
+    for allow in (False, True):
+        cll = core.CellsLogLikelihood(batch, allow_failed_cells=allow)      # does not raise
+        assert np.isnan(cll._dom[1]).all() and np.isnan(cll._cod[1]).all()
+        _close(cll._dom[[0, 2]], g['dom'][[0, 2]])
+        lc = cll.get_raw_lightcurve(tsmin=4)
+        ref = g['rows']
+        assert np.array_equal(np.isnan(lc), np.isnan(ref))
+        assert np.array_equal(lc[1, 3:], [0.0, -1.0, 0.0]) and np.isnan(lc[1, 2])
+        assert np.array_equal(lc[:, 0], ref[:, 0])
+        sc = np.maximum(1.0, np.add.reduceat(np.abs(np.log1p(-g['we'])), off[:-1]))
+        for k in (1, 2, 3, 4):
+            _close(lc[[0, 2], k], ref[[0, 2], k], rtol=1e-8)
+        _close(lc[[0, 2], 5], ref[[0, 2], 5], scale=sc[[0, 2]], rtol=1e-8)
+
+
 def test_spread_cells_on_two_streams_do_not_interleave():
     """Spread cells exchange partial sums through one device array of the library; launches
     on different streams are chained by the library, so calls issued from two streams at
