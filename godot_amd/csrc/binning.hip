@@ -858,7 +858,9 @@ int exposure_at_impl(const ExposureLoad &ld, int64_t n_ft2, const void *table, c
     GODOT_REQUIRE(n_ft2 > 0 && n_t >= 0, GODOT_E_INVALID, "%s: bad sizes", fn);
     GODOT_REQUIRE(ld.tstart && ld.tstop && ld.exposure && ld.livetime && table, GODOT_E_INVALID,
                   "%s: null table pointer", fn);
-    if (n_t == 0) return GODOT_OK;
+    // nothing to write: no query times, or a single one with differences asked for
+    const int64_t n_out = cumulative ? n_t : n_t - 1;
+    if (n_out <= 0) return GODOT_OK;
     GODOT_REQUIRE(times && out_exp && out_sexp && out_bexp, GODOT_E_INVALID, "%s: null query/output pointer", fn);
     GODOT_REQUIRE(workspace && workspace_bytes >= align256(sizeof(Quad) * (size_t)n_t), GODOT_E_WORKSPACE,
                   "%s: workspace smaller than godot_exposure_workspace_bytes(n_t)", fn);
@@ -866,10 +868,8 @@ int exposure_at_impl(const ExposureLoad &ld, int64_t n_ft2, const void *table, c
     Quad *at = (Quad *)workspace;
     hipLaunchKernelGGL(exposure_query_kernel, dim3((unsigned)ceil_div(n_t, 256)), dim3(256), 0, st, ld,
                        (const Quad *)table, n_ft2, times, n_t, at);
-    int64_t n_out = cumulative ? n_t : n_t - 1;
-    if (n_out > 0)
-        hipLaunchKernelGGL(exposure_out_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st,
-                           (const Quad *)at, n_out, cumulative, out_exp, out_sexp, out_bexp, out_dead);
+    hipLaunchKernelGGL(exposure_out_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0, st,
+                       (const Quad *)at, n_out, cumulative, out_exp, out_sexp, out_bexp, out_dead);
     GODOT_LAUNCH_CHECK(fn);
     return GODOT_OK;
 }

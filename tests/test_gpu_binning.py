@@ -35,6 +35,23 @@ def test_exposure_matches_reference(golden):
         assert_same(_n(dd[k]), g['differential'][k], "g['differential'][k]")
 
 
+def test_exposure_between_fewer_than_two_times_is_empty(golden):
+    """cumulative=False differences neighbouring query times (core.py:1836-1841): one time,
+    or none, gives empty arrays like numpy's x[1:] - x[:-1], not an error."""
+    g = golden('exposure.npz')
+    d = _data(g)
+    for times in (g['times'][:1], g['times'][:0]):
+        for dead in (False, True):
+            out = d.get_exposure(times, deadtime_too=dead, cumulative=False)
+            ref = orc.exposure_at(g['in_TSTART'], g['in_TSTOP'], g['in_exposure'], g['in_LIVETIME'], d.S, d.B,
+                                  d.E, times, deadtime_too=dead, cumulative=False)
+            for a, b in zip(out, ref):
+                assert (a is None and b is None) or (_n(a).shape == b.shape == (0,))
+    one = d.get_exposure(g['times'][:1], deadtime_too=True, cumulative=True)
+    for k in range(4):
+        assert_same(_n(one[k]), g['cumulative'][k][:1], 'first cumulative value')
+
+
 @pytest.mark.parametrize('name', ['cells_dense.npz', 'cells_sparse.npz'])
 def test_get_cells_matches_reference(golden, name):
     g = golden(name)
