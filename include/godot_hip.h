@@ -107,7 +107,9 @@ int godot_profile_quantiles(const double *dom, const double *cod,
 /* Assemble light-curve rows 1..5 of get_raw_lightcurve (core.py:1329-1334):
  * out[c] = {terr_days, alpha|UL, err_lo|0, err_hi|-1, TS}; column 0 (MJD of the
  * cell mid-time) is formed on the host in extended precision as the reference
- * does (core.py:24-26).                                                       */
+ * does (core.py:24-26).  NaN quantiles (a profile the reference filled with NaN
+ * without stopping) take their places in the row as they do there; a NaN alpha
+ * (a cell the reference raises on) gives a row of NaN.                        */
 int godot_lightcurve_rows(const double *tstart, const double *tstop,
                           const double *alpha, const double *ts,
                           const double *xlo, const double *xhi,
@@ -176,7 +178,9 @@ int godot_exposure_table(const double *tstart, const double *tstop,
 /* Exposure, source-scaled exposure, background-scaled exposure and dead time
  * at the query times (cumulative != 0) or between consecutive query times
  * (cumulative == 0: outputs have n_t - 1 entries).  Replaces
- * Data.get_exposure (core.py:1806-1841).  out_dead may be NULL.
+ * Data.get_exposure (core.py:1806-1841).  out_dead may be NULL.  With nothing
+ * to write (n_t == 0, or n_t == 1 and cumulative == 0) the call succeeds and
+ * looks at no query, output or workspace pointer.
  * workspace: godot_exposure_workspace_bytes(n_t).                             */
 size_t godot_exposure_workspace_bytes(int64_t n_t);
 int godot_exposure_at(const double *tstart, const double *tstop,
