@@ -1186,9 +1186,9 @@ class Data(object):
         if ncell == 0:
             tcell = tstop - tstart
             ncell = 1
-        edges_h = tstart + np.arange(ncell + 1) * tcell
-        assert(edges_h[-1] <= tstop)
         if use_barycenter:
+            edges_h = tstart + np.arange(ncell + 1) * tcell
+            assert(edges_h[-1] <= tstop)
             # uniform cells at the barycentre: nonuniform edges at the observatory, which
             # is where exposure (and, for topocentric photon times, the binning) is done
             topo_h = np.array(self._bary2topo(edges_h), dtype=np.float64)
@@ -1196,18 +1196,34 @@ class Data(object):
             topo_h[0] = self._t0   # fix tiny numerical error
             assert(topo_h[-1] <= self._t1)
             bary_h = edges_h
+            self._topo_edges_v = topo_h.copy()
         else:
-            topo_h = bary_h = edges_h
-        self._topo_edges = topo_h.copy()
+            # tstart + arange(ncell + 1) * tcell (core.py:2071) formed on the device: the same
+            # two roundings per edge (i * tcell, then + tstart), so the same bits, without
+            # half a million edges made on the host and uploaded
+            assert(tstart + ncell * tcell <= tstop)
+            topo_h = bary_h = torch.arange(ncell + 1, dtype=F64, device=self.device) * tcell + tstart
+            self._topo_edges_v = topo_h
 
         # apply scales if provided (reverted before returning, as the reference does)
         ov = self.apply_scalers(src_scaler=src_scaler, bkg_scaler=bkg_scaler)
         try:
             return self._cells_on_edges(topo_h, bary_h, ft1_is_bary, use_barycenter, trim_zero_exposure,
                                         time_series_only, randomize, seed, src_injector,
-                                        minimum_fractional_exposure)
+                                        minimum_fractional_exposure, first_edge_dev=tstart)
         finally:
             self.revert_scalers(ov)
+
+    @property
+    def _topo_edges(self):
+        """Topocentric cell edges of the last get_cells call, as a host array (the reference
+        keeps them under this name, core.py:2081)."""
+        v = self.__dict__.get('_topo_edges_v')
+        if v is None:
+            raise AttributeError('_topo_edges')
+        if isinstance(v, torch.Tensor):
+            v = self._topo_edges_v = _np(v)
+        return v
 
     def set_barycenter_converters(self, topo2bary, bary2topo):
         """Callables mapping arrays of topocentric METs to barycentric ones and back: what
@@ -1223,17 +1239,20 @@ class Data(object):
         return np.asarray(self._b2t(np.asarray(bary_times, dtype=np.float64)), dtype=np.float64)
 
     def _cells_on_edges(self, topo_h, bary_h, ft1_is_bary, use_barycenter, trim_zero_exposure,
-                        time_series_only, randomize, seed, src_injector, minimum_fractional_exposure):
+                        time_series_only, randomize, seed, src_injector, minimum_fractional_exposure,
+                        first_edge_dev=None):
         """The array tail of get_cells (reference core.py:2087-2206).  topo_h: cell edges
         at the observatory (exposure); bary_h: the same edges at the barycentre (equal to
         topo_h without barycentring).  Photons are binned on the edges of their own time
         system; the cells are labelled with the barycentric edges when barycentring."""
         dev = self.device
-        topo = torch.from_numpy(np.ascontiguousarray(topo_h)).to(dev)
+        on_device = isinstance(topo_h, torch.Tensor)      # uniform edges made on the device
+        topo = topo_h if on_device else torch.from_numpy(np.ascontiguousarray(topo_h)).to(dev)
         # always use topocentric times to manage the exposure calculation
         exp, sexp, bexp, dead = self.get_exposure(topo, deadtime_too=True, cumulative=False)
         edges_h = bary_h if ft1_is_bary else topo_h
         edges = topo if edges_h is topo_h else torch.from_numpy(np.ascontiguousarray(edges_h)).to(dev)
+        first_edge = first_edge_dev if on_device else float(edges_h[0])
         starts, stops = edges[:-1].contiguous(), edges[1:].contiguous()
         relabel = use_barycenter and not ft1_is_bary
         if relabel or use_barycenter:
@@ -1248,7 +1267,7 @@ class Data(object):
             sexp[m] = 0
             bexp[m] = 0
 
-        lo, hi, counts = ops.bin_photons(self.ti, float(edges_h[0]), stops)
+        lo, hi, counts = ops.bin_photons(self.ti, first_edge, stops)
 
         if trim_zero_exposure:
             keep = ops.select_cells(exp, 0.0)
@@ -1278,7 +1297,8 @@ class Data(object):
             sexp_h, bexp_h = _np(sexp), _np(bexp)
             if src_injector is not None:
                 # the injector is handed ALL barycentric edges, as in the reference (2135)
-                csexp = np.cumsum(src_injector(bary_h[:-1], bary_h[1:]) * sexp_h)
+                bh = _np(bary_h) if on_device else bary_h
+                csexp = np.cumsum(src_injector(bh[:-1], bh[1:]) * sexp_h)
             else:
                 csexp = np.cumsum(sexp_h)
             csexp *= 1. / csexp[-1]
