@@ -151,10 +151,12 @@ def main():
     cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
     torch.cuda.synchronize()
     t_bin_first = time.perf_counter() - t0
+    # with the running sums of the exposure table cached: mean of five calls
     t0 = time.perf_counter()
-    cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+    for _ in range(5):
+        cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
     torch.cuda.synchronize()
-    t_bin_again = time.perf_counter() - t0
+    t_bin_again = (time.perf_counter() - t0) / 5
     cr = cells.ranges()
     ncell = cr.ncell
     nph_in = int((cr.hi - cr.lo).sum().cpu())
