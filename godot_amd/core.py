@@ -819,10 +819,18 @@ class CellsLogLikelihood(object):
         if self.allow_failed_cells:
             # cells the reference would have stopped at: no number in their rows
             rows[(self._flags & 0x10) != 0] = float('nan')
-        out = np.empty([len(self.cells), 6])
-        out[:, 1:] = _np(rows)
-        tmid = _np(0.5 * (self.cells.starts + self.cells.stops))
-        out[:, 0] = met2mjd(tmid)
+        # the six columns are put together on the device, so that the host receives the array
+        # it hands out in one copy; the MJD column with the reference's extended-precision
+        # roundings restated in integers (times the restatement does not cover come back
+        # NaN and are done on the host, as the reference does all of them)
+        tmid = 0.5 * (self.cells.starts + self.cells.stops)
+        out_d = torch.empty((len(self.cells), 6), dtype=F64, device=rows.device)
+        out_d[:, 1:] = rows
+        out_d[:, 0] = ops.met2mjd(tmid, MJDREF)
+        out = _np(out_d)
+        left = np.isnan(out[:, 0])
+        if left.any():
+            out[left, 0] = met2mjd(_np(tmid)[left])
         return out
 
 

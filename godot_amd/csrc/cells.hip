@@ -603,7 +603,83 @@ __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop
     (void)S;
 }
 
+// met * (1 / 86400) + mjdref as the reference forms it (core.py:24-26): in the 80-bit
+// extended precision of numpy's longdouble on x86 (64-bit significand, round to nearest
+// even after the product and after the sum), then rounded to double where the value is
+// stored.  Restated in integer arithmetic: exact 106-bit product, each rounding done on
+// the integer significand.  Positive normal operands whose sum fits 128 bits after
+// alignment; anything else yields NaN and is left to the caller.
+__device__ __forceinline__ int top_bit(unsigned __int128 v)
+{
+    const unsigned long long hi = (unsigned long long)(v >> 64), lo = (unsigned long long)v;
+    return hi ? 128 - __builtin_clzll(hi) : (lo ? 64 - __builtin_clzll(lo) : 0);
+}
+
+// v (a significand of more than `keep` bits) rounded to nearest even at `keep` bits;
+// e is the exponent of v's unit and follows the shift
+__device__ __forceinline__ unsigned __int128 round_bits(unsigned __int128 v, int keep, int &e)
+{
+    const int nb = top_bit(v);
+    if (nb <= keep) return v;
+    int sh = nb - keep;
+    unsigned __int128 q = v >> sh;
+    const unsigned __int128 rem = v & ((((unsigned __int128)1) << sh) - 1);
+    const unsigned __int128 half = ((unsigned __int128)1) << (sh - 1);
+    if (rem > half || (rem == half && (q & 1))) ++q;
+    if (top_bit(q) > keep) {
+        q >>= 1;        // the carry ran through: a power of two, nothing is lost
+        ++sh;
+    }
+    e += sh;
+    return q;
+}
+
+__device__ __forceinline__ bool split_positive_normal(double x, unsigned long long &mant, int &e)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int be = (int)((b >> 52) & 0x7ff);
+    if ((b >> 63) || be == 0 || be == 0x7ff) return false;
+    mant = (b & ((1ull << 52) - 1)) | (1ull << 52);
+    e = be - 1075;
+    return true;
+}
+
+__global__ void met2mjd_kernel(const double *met, int64_t n, double per_day, double mjdref, double *mjd)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long mt, mc, mm;
+    int et, ec, em;
+    double out = qnan();
+    if (split_positive_normal(met[i], mt, et) && split_positive_normal(per_day, mc, ec) &&
+        split_positive_normal(mjdref, mm, em)) {
+        int ep = et + ec;
+        const unsigned __int128 p = round_bits((unsigned __int128)mt * mc, 64, ep);    // fl80(t * c)
+        const int elow = ep < em ? ep : em;
+        const int dp = ep - elow, dm = em - elow;
+        if (dp <= 60 && dm <= 60) {
+            int es = elow;
+            unsigned __int128 sum = (p << dp) + (((unsigned __int128)mm) << dm);
+            sum = round_bits(sum, 64, es);                                             // fl80(. + mjdref)
+            sum = round_bits(sum, 53, es);                                             // stored as double
+            out = ldexp((double)(unsigned long long)sum, es);
+        }
+    }
+    mjd[i] = out;
+}
+
 }   // namespace
+
+extern "C" int godot_met2mjd(const double *met, int64_t n, double mjdref, double *mjd, godot_stream_t stream)
+{
+    GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_met2mjd: negative n");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(met && mjd, GODOT_E_INVALID, "godot_met2mjd: null pointer");
+    hipLaunchKernelGGL(met2mjd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, met, n,
+                       1. / 86400, mjdref, mjd);
+    GODOT_LAUNCH_CHECK("godot_met2mjd");
+    return GODOT_OK;
+}
 
 extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                               const double *S, const double *B, int64_t ncell, const double *guess,

@@ -169,6 +169,16 @@ def lightcurve_rows(tstart, tstop, alpha, ts, xlo, xhi, S, tsmin):
     return rows
 
 
+def met2mjd(met, mjdref):
+    """MJD of mission elapsed times with the reference's extended-precision roundings
+    (core.py:24-26); NaN where the integer restatement does not apply."""
+    _dev_check(met, F64, 'met')
+    out = torch.empty_like(met)
+    with torch.cuda.device(met.device):
+        _lib.call('godot_met2mjd', _p(met), met.numel(), float(mjdref), _p(out), _stream(met.device))
+    return out
+
+
 def cell_beta_max(cr, alpha, guess=1.0, swap=False, want_logl=True):
     n, dev = cr.ncell, cr.device
     at, a0 = _per_cell(alpha, n, dev, 'alpha')

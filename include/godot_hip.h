@@ -117,6 +117,15 @@ int godot_lightcurve_rows(const double *tstart, const double *tstop,
                           double *rows /* [ncell][5] */,
                           godot_stream_t stream);
 
+/* Mission elapsed time (s) to MJD: met2mjd (core.py:24-26), bit for bit what the
+ * reference stores: the product with 1/86400 and the sum with mjdref each rounded
+ * to the 64-bit significand of numpy's longdouble on x86, the result then to
+ * double.  Integer arithmetic on the device.  Defined for positive normal met
+ * and mjdref; other inputs (zero, negative, subnormal, non-finite, or operands
+ * more than 60 binary orders apart) give NaN for the caller to treat.           */
+int godot_met2mjd(const double *met, int64_t n, double mjdref, double *mjd,
+                  godot_stream_t stream);
+
 /* Background level maximising logL at fixed alpha: get_beta_max
  * (core.py:741-823) and the profile likelihood built on it
  * (log_profile_likelihood, core.py:391-406).  alpha per cell or alpha0.

@@ -504,6 +504,30 @@ def test_profile_of_only_nan_takes_its_place_in_the_light_curve(golden):
         _close(lc[[0, 2], 5], ref[[0, 2], 5], scale=sc[[0, 2]], rtol=1e-8)
 
 
+def test_met2mjd_is_the_extended_precision_result_bit_for_bit():
+    """met2mjd (core.py:24-26) works in numpy's longdouble (64-bit significand on x86) and
+    the light curve stores the result as double: two roundings in extended precision, then
+    one to double.  The device restates them in integers; plain double arithmetic differs
+    from the reference in about 6 % of the values."""
+    from godot_amd import core, ops
+    if np.finfo(np.longdouble).nmant != 63:
+        pytest.skip('numpy longdouble is not the x87 extended format on this host')
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    t = np.concatenate([2.4e8 + rng.random(300000) * 5e8, rng.random(50000) * 1e3,
+                        10.0 ** rng.uniform(-5, 14, 50000),
+                        86400. * rng.integers(1, 100000, 50000).astype(float),
+                        2.4e8 + np.arange(50000) * 600. + 300])
+    ref = np.asarray(core.met2mjd(t), dtype=np.float64)
+    got = ops.met2mjd(torch.from_numpy(t).to(dev), core.MJDREF).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert (t * (1. / 86400) + core.MJDREF != ref).sum() > 1000       # the comparison has teeth
+    # outside the restatement: NaN, never a wrong number
+    odd = np.array([0.0, -5.0, np.inf, np.nan, 5e-324, 1e300])
+    got = ops.met2mjd(torch.from_numpy(odd).to(dev), core.MJDREF).cpu().numpy()
+    assert np.isnan(got).all()
+
+
 def test_spread_cells_on_two_streams_do_not_interleave():
     """Spread cells exchange partial sums through one device array of the library; launches
     on different streams are chained by the library, so calls issued from two streams at
