@@ -569,6 +569,113 @@ __global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *do
     }
 }
 
+// The same for profiles of at most 256 points (the light curves use 200 and 100): lane l
+// keeps points 4l .. 4l+3 in registers, adds its own trapezoids serially and the wavefront
+// scans the 64 lane totals once, where the kernel above scans every chunk of 64 points and
+// stages the row in LDS.  Same results up to the order of the additions.
+__global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *dom, const double *cod,
+                                                                 int64_t ncell, int npt, double c_lo,
+                                                                 double c_hi, double *aguess,
+                                                                 double *xlo, double *xhi)
+{
+    const int lane = threadIdx.x % WAVE;
+    const int64_t cell = (int64_t)blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    if (cell >= ncell) return;                  // whole wavefronts leave together
+    const double *dp = dom + cell * npt;
+    const double *cp = cod + cell * npt;
+    const int i0 = 4 * lane;
+    const int nseg = npt - 1;
+    double d[5], pdf[5];
+    double best = -INFINITY;
+    int ibest = npt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        const bool in = i < npt;
+        const int ii = in ? i : npt - 1;
+        const double v = cp[ii];
+        d[k] = dp[ii];
+        pdf[k] = in ? exp(v) : 0.0;
+        if (in && v > best) {
+            best = v;
+            ibest = i;
+        }
+    }
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(ibest, o, WAVE);
+        if (ob > best || (ob == best && oi < ibest)) {
+            best = ob;
+            ibest = oi;
+        }
+    }
+    // point 4l+4 belongs to the next lane
+    d[4] = __shfl_down(d[0], 1, WAVE);
+    pdf[4] = __shfl_down(pdf[0], 1, WAVE);
+    // inclusive sums of this lane's trapezoids: s[k] = seg(i0) + ... + seg(i0 + k)
+    double s[4];
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k;
+        if (i < nseg) run += (d[k + 1] - d[k]) * (pdf[k + 1] + pdf[k]) / 2.0;
+        s[k] = run;
+    }
+    double incl = run;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const double u = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += u;
+    }
+    // cdf[i0]: the sum of the lanes below; cdf[i0 + k + 1] = before + s[k]
+    const double below = __shfl_up(incl, 1, WAVE);
+    const double before = lane == 0 ? 0.0 : below;
+    const double total = __shfl(incl, WAVE - 1, WAVE);
+    const double inv = 1. / total;
+    const double conf[2] = {c_lo, c_hi};
+    double res[2];
+    double ag = qnan();
+    {
+        // dom[ibest] sits in lane ibest / 4
+        const int src = ibest < npt ? ibest / 4 : 0;
+        const int kk = ibest & 3;
+        const double mine = kk == 0 ? d[0] : (kk == 1 ? d[1] : (kk == 2 ? d[2] : d[3]));
+        const double v = __shfl(mine, src, WAVE);
+        if (ibest < npt) ag = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        // searchsorted(cdf, conf) (side='left'): the first index whose cdf reaches conf
+        int kfirst = 4;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+            if (i0 + k < nseg && (before + s[k]) * inv >= conf[q]) kfirst = k;
+        const unsigned long long m = __ballot(kfirst < 4 ? 1 : 0);
+        double r = qnan();
+        const bool at0 = (0.0 * inv >= conf[q]);              // cdf[0] = 0 reaches it: index 0, no interval
+        if (m != 0 && !at0) {
+            const int src = __builtin_ctzll(m);
+            double mine = qnan();
+            if (kfirst < 4) {
+                const double chi = (before + (kfirst == 0 ? s[0] : kfirst == 1 ? s[1] : kfirst == 2 ? s[2] : s[3])) * inv;
+                const double clo = (kfirst == 0 ? before : before + (kfirst == 1 ? s[0] : kfirst == 2 ? s[1] : s[2])) * inv;
+                const double dhi = kfirst == 0 ? d[1] : kfirst == 1 ? d[2] : kfirst == 2 ? d[3] : d[4];
+                const double dlo = kfirst == 0 ? d[0] : kfirst == 1 ? d[1] : kfirst == 2 ? d[2] : d[3];
+                const double slope = (chi - clo) / (dhi - dlo);
+                mine = dlo + (conf[q] - clo) / slope;
+            }
+            r = __shfl(mine, src, WAVE);
+        }
+        res[q] = r;
+    }
+    if (lane == 0) {
+        aguess[cell] = ag;
+        xlo[cell] = res[0];
+        xhi[cell] = res[1];
+    }
+}
+
 // rows 1..5 of get_raw_lightcurve (core.py:1318-1334)
 __global__ void lightcurve_rows_kernel(const double *tstart, const double *tstop, const double *alpha,
                                        const double *ts, const double *xlo, const double *xhi,
@@ -818,8 +925,12 @@ extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int
     hipStream_t st = (hipStream_t)stream;
     size_t smem = (size_t)4 * 3 * npt * sizeof(double);
     dim3 grid((unsigned)ceil_div(ncell, 4));
-    hipLaunchKernelGGL(profile_quantiles_kernel, grid, dim3(256), smem, st, dom, cod, ncell, npt,
-                       conf_lo, conf_hi, aguess, xlo, xhi);
+    if (npt <= 256)
+        hipLaunchKernelGGL(profile_quantiles4_kernel, grid, dim3(256), 0, st, dom, cod, ncell, npt,
+                           conf_lo, conf_hi, aguess, xlo, xhi);
+    else
+        hipLaunchKernelGGL(profile_quantiles_kernel, grid, dim3(256), smem, st, dom, cod, ncell, npt,
+                           conf_lo, conf_hi, aguess, xlo, xhi);
     GODOT_LAUNCH_CHECK("godot_profile_quantiles");
     return GODOT_OK;
 }

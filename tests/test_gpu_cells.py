@@ -504,6 +504,43 @@ def test_profile_of_only_nan_takes_its_place_in_the_light_curve(golden):
         _close(lc[[0, 2], 5], ref[[0, 2], 5], scale=sc[[0, 2]], rtol=1e-8)
 
 
+@pytest.mark.parametrize('npt', [2, 3, 5, 63, 64, 65, 100, 200, 255, 256, 257, 300, 1000])
+def test_profile_quantiles_match_oracle_at_any_length(npt):
+    """Quantiles of the normalised profile (core.py:1247-1256) on random profiles: both kernels
+    (rows of at most 256 points in registers, longer ones through LDS), non-uniform abscissae,
+    peaks at either end, ties, a row of only NaN, a -inf entry."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(npt)
+    ncell = 300
+    dom = np.sort(rng.uniform(0, 5, (ncell, npt)), axis=1) + np.arange(npt) * 1e-3
+    mu = rng.uniform(-1, 6, (ncell, 1))
+    sig = rng.uniform(0.05, 3, (ncell, 1))
+    cod = -0.5 * ((dom - mu) / sig) ** 2
+    cod[::7] = np.round(cod[::7], 1)          # ties for the arg-max
+    cod[5] = np.nan                           # a profile of only NaN
+    cod[6, npt // 2] = -np.inf
+    for conf in ((0.159, 0.841), (0.05, 0.95), (0.001, 0.999)):
+        ag, xlo, xhi = [x.cpu().numpy() for x in ops.profile_quantiles(
+            torch.from_numpy(dom).to(dev), torch.from_numpy(cod).to(dev), conf[0], conf[1])]
+        for i in range(ncell):
+            with np.errstate(all='ignore'):
+                ref_ag = dom[i][np.argmax(cod[i])] if not np.isnan(cod[i]).all() else np.nan
+                try:
+                    ref = orc.flux_quantiles(dom[i], cod[i].copy(), list(conf))
+                except IndexError:
+                    ref = None                 # searchsorted ran off the end: numpy raises
+            if np.isnan(cod[i]).all():
+                assert np.isnan(ag[i]) and np.isnan(xlo[i]) and np.isnan(xhi[i])
+                continue
+            assert ag[i] == ref_ag, (i, ag[i], ref_ag)
+            if ref is None:
+                continue
+            for got, want in ((xlo[i], ref[0]), (xhi[i], ref[1])):
+                if np.isfinite(want):
+                    assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (npt, conf, i, got, want)
+
+
 def test_met2mjd_is_the_extended_precision_result_bit_for_bit():
     """met2mjd (core.py:24-26) works in numpy's longdouble (64-bit significand on x86) and
     the light curve stores the result as double: two roundings in extended precision, then
