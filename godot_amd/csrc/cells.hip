@@ -895,7 +895,7 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     int gl, gr;
-    if (godot_detail::block_cells(nph, ncell)) {
+    if (godot_detail::logpdf_block_cells(nph, ncell)) {
         godot_detail::logpdf_block_launch(we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero, swap, dom,
                                           cod, flags, st);
     } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {

@@ -864,6 +864,14 @@ bool block_cells(int64_t nph, int64_t ncell)
     return ncell > 0 && (double)nph >= 16384.0 * (double)ncell;
 }
 
+// Profile grids take a workgroup per cell also where the cells are only moderately large but
+// few: the dense-cell kernel puts 16 cells into a workgroup, and with fewer than a thousand
+// such workgroups most SIMDs hold a single wavefront and nothing hides its latencies.
+bool logpdf_block_cells(int64_t nph, int64_t ncell)
+{
+    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)nph >= 1024.0 * (double)ncell);
+}
+
 void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
                       const double *B, int64_t ncell, const double *guess, double guess0, const double *beta,
                       double beta0, int swap, double *alpha, double *ts, int32_t *flags, hipStream_t st)

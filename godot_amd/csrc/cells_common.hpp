@@ -13,6 +13,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
                       hipStream_t st);
 // very large cells, one workgroup each (cells_block.hip)
 bool block_cells(int64_t nph, int64_t ncell);
+bool logpdf_block_cells(int64_t nph, int64_t ncell);
 void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
                       const double *B, int64_t ncell, const double *guess, double guess0, const double *beta,
                       double beta0, int swap, double *alpha, double *ts, int32_t *flags, hipStream_t st);
@@ -613,11 +614,16 @@ __device__ Support support_search(const CD &cd, double S, double aopt, double dl
     Support r;
     double amin = 0.0, amax, llmax;
     double acc[2];
-    // logL(a) + S a and its derivative + S; alpha w + (1 - w) formed as 1 + (alpha - 1) w
+    // logL(a) + S a and its derivative + S; alpha w + (1 - w) formed as 1 + (alpha - 1) w.
+    // A Newton step of the searches below can land on a flux at which some factor is
+    // negative: the reference's sum of logarithms is NaN there and so is everything it
+    // returns (core.py:876-878, 891-893).  The logarithm of the product would hide an even
+    // number of such factors, so a negative factor (its reciprocal is negative) makes the
+    // derivative sum NaN, which the step then carries into the end of the support.
     auto f0f1 = [&](double a) {
         const double am1 = a - 1.0;
         cd.logsum_rcp([=](double w) { return fma(am1, w, 1.0); },
-                      [](double w, double x) { return w * x; }, acc[0], acc[1]);
+                      [](double w, double x) { return x < 0.0 ? qnan() : w * x; }, acc[0], acc[1]);
     };
     if (aopt == 0) {   // core.py:869-880
         cd.logsum_rcp([](double w) { return 1.0 - w; },
