@@ -101,16 +101,30 @@ __device__ __noinline__ void fit_joint(const StreamCell<T> &cd, double S, double
         } else {
             db = gb / acc[4];
         }
-        double s = 1.0, x = al, y = be, Ln = L;
+        double x = al, y = be, Ln = L;
         bool moved = false;
-        for (int h = 0; h < 40; ++h, s *= 0.5) {
-            x = fmax(0.0, al + s * da);
-            y = fmax(0.0, be + s * db);
-            if (x == 0 && y == 0) continue;
-            Ln = full_loglike(cd, S, B, x, y);
-            if (Ln >= L) {
-                moved = true;
-                break;
+        // Two tries: the Newton step, then the same gradient scaled by the diagonal of the
+        // curvature alone.  A coupled step whose one component is cut off at its bound during
+        // the search (a variable a hair above zero is not "on" the bound) can point downhill
+        // in the other; the diagonal step keeps the sign of each gradient component, which
+        // the projection onto the quadrant cannot turn around.
+        for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
+            if (attempt == 1) {
+                if (!(fa && fb)) break;             // the step was a diagonal one already
+                da = ga / acc[2];
+                db = gb / acc[4];
+            }
+            double s = 1.0;
+            for (int h = 0; h < 40; ++h, s *= 0.5) {
+                x = fmax(0.0, al + s * da);
+                y = fmax(0.0, be + s * db);
+                if (x == 0 && y == 0) continue;
+                if (x == al && y == be) break;      // the step no longer changes the point
+                Ln = full_loglike(cd, S, B, x, y);
+                if (Ln >= L) {
+                    moved = true;
+                    break;
+                }
             }
         }
         if (!moved) break;
