@@ -93,6 +93,8 @@ SIGNATURES = {
                                                        c_f64p, c_f64p, c_ws, c_size, c_stream]),
     'godot_search_sorted': (c_int, [c_f64p, c_i64, c_f64p, c_i64, c_int, c_i64p, c_stream]),
     'godot_piecewise_lookup': (c_int, [c_f64p, c_f64p, c_i64, c_f64p, c_i64, c_f64p, c_stream]),
+    'godot_piecewise_average': (c_int, [c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_i64, c_f64p, c_f64p, c_i64, c_f64p,
+                                        c_stream]),
     'godot_rescale_weights': (c_int, [c_f64p, c_f64p, c_f64, c_f64p, c_f64, c_i64, c_f64p, c_stream]),
     'godot_bb_workspace_bytes': (c_size, [c_i64, c_int]),
     'godot_bb_fitness': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_int, c_i64, c_i64, c_ws, c_f64p, c_f64p,

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .scalers import PiecewiseScaler
 
 __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries',
            'CellLogLikelihood', 'CellsLogLikelihood', 'CellsLogLikelihoodOld', 'Data',
@@ -660,10 +661,10 @@ class CellsLogLikelihood(object):
         """Report cells with a suspiciously narrow support or a profile that does not peak at
         its maximum (reference core.py:1100-1106)."""
         dx = self._dom[:, -1] - self._dom[:, 0]
-        bad_x = _np(torch.nonzero(dx.abs() < 1e-3).ravel())
+        bad_x = np.ravel(np.argwhere(np.abs(dx) < 1e-3))
         print('Indices with suspiciously narrow support ranges: ', bad_x)
-        ymax = self._cod.max(dim=1).values
-        bad_y = _np(torch.nonzero(ymax.abs() > 0.2).ravel())
+        ymax = self._cod.max(axis=1)
+        bad_y = np.ravel(np.argwhere(np.abs(ymax) > 0.2))
         print('Indices where there is a substantial disagreement in the optimized value of the log '
               'likelihood and the codomain: ', bad_y)
         return bad_x, bad_y
@@ -678,7 +679,8 @@ class CellsLogLikelihood(object):
             _, lp1, _ = ops.cell_beta_max(self._cr, aopt, swap=self._swap)
             _, lp0, _ = ops.cell_beta_max(self._cr, 0.0, swap=self._swap)
             ts = 2 * (lp1 - lp0)
-            ts = torch.where((aopt == 0) | (self._cr.S == 0), torch.zeros_like(ts), ts)
+            s_eff = self._cr.B if self._swap else self._cr.S     # what get_ts tests: core.py:982-984, 343-345
+            ts = torch.where((aopt == 0) | (s_eff == 0), torch.zeros_like(ts), ts)
             return aopt, ts, xlo, xhi
         aopt, ts, fl = ops.cell_fit(self._cr, guess=ag, beta=1.0, swap=self._swap)
         _raise_as_reference(fl, self.allow_failed_cells)
@@ -770,7 +772,8 @@ class CellsLogLikelihood(object):
             _, lp1, _ = ops.cell_beta_max(cr, aopt, swap=self._swap)
             _, lp0, _ = ops.cell_beta_max(cr, 0.0, swap=self._swap)
             ts = 2 * (lp1 - lp0)
-            ts = torch.where((aopt == 0) | (cr.S == 0), torch.zeros_like(ts), ts)
+            s_eff = cr.B if self._swap else cr.S                 # what get_ts tests: core.py:982-984, 343-345
+            ts = torch.where((aopt == 0) | (s_eff == 0), torch.zeros_like(ts), ts)
         else:
             aopt, ts, fl = ops.cell_fit(cr, swap=self._swap)
             if bool((fl & 0x10).any().cpu()):
@@ -1008,7 +1011,10 @@ class Data(object):
         key = (id(src_scaler), id(bkg_scaler))
         cached = self._scaled_tables.get(('rows',) + key)
         if cached is None:
-            T0, T1 = self._ft2()
+            # the rows of the spacecraft table stay on the device; a scaler of another kind
+            # (any callable of host arrays, as in the reference) gets host arrays
+            dev_ok = all(s is None or isinstance(s, PiecewiseScaler) for s in (src_scaler, bkg_scaler))
+            T0, T1 = (self.TSTART, self.TSTOP) if dev_ok else self._ft2()
             sexp = self.exposure * (self.S / self.E)
             bexp = self.exposure * (self.B / self.E)
             if src_scaler is not None:

@@ -800,6 +800,39 @@ __global__ void piecewise_lookup_kernel(const double *stops, const double *scale
     out[k] = scales[i < nseg ? i : nseg - 1];
 }
 
+// Mean of a piecewise-constant function over the intervals t0[k] .. t1[k]
+// (PiecewiseScaler.__call__ with two arguments, scalers.py:52-85): the value of the
+// segment when the interval lies inside one, else the two partial segments at its ends
+// plus the whole segments between them (one: its own product; several: a difference of
+// the running sums of the products), divided by the length.  starts/stops/scales are the
+// scaler's padded segment arrays, prod = (stops - starts) * scales and cprod its running
+// sum, both rounded from extended precision as the reference stores them.  An interval
+// that begins exactly where a segment ends belongs to the next segment.
+__global__ void piecewise_average_kernel(const double *starts, const double *stops, const double *scales,
+                                         const double *prod, const double *cprod, int64_t nseg,
+                                         const double *t0, const double *t1, int64_t n, double *out)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double a = t0[k], b = t1[k];
+    int64_t i0 = lower_bound(stops, nseg, a);
+    const int64_t i1 = lower_bound(stops, nseg, b);
+    if (i0 < nseg && a == stops[i0]) ++i0;
+    const int64_t last = nseg - 1;
+    const int64_t j0 = i0 < last ? i0 : last, j1 = i1 < last ? i1 : last;
+    if (i0 == i1) {
+        out[k] = scales[j0];
+        return;
+    }
+    const double ends = scales[j1] * (b - starts[j1]) + scales[j0] * (stops[j0] - a);
+    const int64_t between = i1 - i0 - 1;
+    const int64_t f = j0 + 1 < last ? j0 + 1 : last;
+    double whole = 0.0;
+    if (between == 1) whole = prod[f];
+    else if (between > 1) whole = cprod[j1] - cprod[f];
+    out[k] = (ends + whole) / (b - a);
+}
+
 // w' = a w / (a w + b (1 - w))  (apply_scalers, core.py:2304); a, b per photon or one value
 __global__ void rescale_weights_kernel(const double *w, const double *a, double a0, const double *b,
                                        double b0, int64_t n, double *out)
@@ -939,6 +972,20 @@ extern "C" int godot_search_sorted(const double *sorted, int64_t n, const double
     hipLaunchKernelGGL(search_sorted_kernel, dim3((unsigned)ceil_div(nv, 256)), dim3(256), 0,
                        (hipStream_t)stream, sorted, n, values, nv, right, out);
     GODOT_LAUNCH_CHECK("godot_search_sorted");
+    return GODOT_OK;
+}
+
+extern "C" int godot_piecewise_average(const double *starts, const double *stops, const double *scales,
+                                       const double *prod, const double *cprod, int64_t nseg, const double *t0,
+                                       const double *t1, int64_t n, double *out, godot_stream_t stream)
+{
+    GODOT_REQUIRE(nseg > 0 && n >= 0, GODOT_E_INVALID, "godot_piecewise_average: bad sizes");
+    if (n == 0) return GODOT_OK;
+    GODOT_REQUIRE(starts && stops && scales && prod && cprod && t0 && t1 && out, GODOT_E_INVALID,
+                  "godot_piecewise_average: null argument");
+    hipLaunchKernelGGL(piecewise_average_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, starts, stops, scales, prod, cprod, nseg, t0, t1, n, out);
+    GODOT_LAUNCH_CHECK("godot_piecewise_average");
     return GODOT_OK;
 }
 

@@ -315,6 +315,23 @@ def search_sorted(sorted_vals, values, side='left'):
     return out
 
 
+def piecewise_average(starts, stops, scales, prod, cprod, t0, t1):
+    """Mean of the piecewise-constant function over each interval t0[k] .. t1[k]."""
+    for x, nm in ((starts, 'starts'), (stops, 'stops'), (scales, 'scales'), (prod, 'prod'), (cprod, 'cprod'),
+                  (t0, 't0'), (t1, 't1')):
+        _dev_check(x, F64, nm)
+    n = stops.numel()
+    if n == 0 or any(x.numel() != n for x in (starts, scales, prod, cprod)):
+        raise ValueError('the segment arrays must be non-empty and of equal length')
+    if t0.numel() != t1.numel():
+        raise ValueError('t0 and t1 must have the same length')
+    out = torch.empty(t0.numel(), dtype=F64, device=t0.device)
+    with torch.cuda.device(t0.device):
+        _lib.call('godot_piecewise_average', _p(starts), _p(stops), _p(scales), _p(prod), _p(cprod), n, _p(t0),
+                  _p(t1), t0.numel(), _p(out), _stream(t0.device))
+    return out
+
+
 def piecewise_lookup(stops, scales, t):
     """scales[searchsorted(stops, t)] for event times t."""
     for x, nm in ((stops, 'stops'), (scales, 'scales'), (t, 't')):

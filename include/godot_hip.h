@@ -231,6 +231,16 @@ int godot_piecewise_lookup(const double *stops, const double *scales, int64_t ns
                            const double *t, int64_t n, double *out,
                            godot_stream_t stream);
 
+/* out[k] = mean over t0[k] .. t1[k] of the piecewise-constant function:
+ * PiecewiseScaler called with the starts and stops of the spacecraft rows
+ * (scalers.py:52-85; apply_scalers core.py:2297-2300 calls it on every row of
+ * the exposure table).  starts/stops/scales/prod/cprod [nseg] are the scaler's
+ * padded arrays (scalers.py:21-29).                                            */
+int godot_piecewise_average(const double *starts, const double *stops, const double *scales,
+                            const double *prod, const double *cprod, int64_t nseg,
+                            const double *t0, const double *t1, int64_t n, double *out,
+                            godot_stream_t stream);
+
 /* out = a w / (a w + b (1 - w)) (apply_scalers, core.py:2304); a, b per photon
  * (device arrays) or NULL for the scalars a0, b0.                              */
 int godot_rescale_weights(const double *w, const double *a, double a0,

@@ -786,6 +786,70 @@ def test_profile_background_lightcurve_close_to_reference(golden):
     assert np.array_equal(lc[:, 0], ref[:, 0]) and np.allclose(lc[:, 1], ref[:, 1], rtol=1e-12)
 
 
+def test_batch_sanity_check_reports_as_the_reference_does(golden, capsys):
+    """CellsLogLikelihood.sanity_check (reference core.py:1100-1106): indices of cells with a
+    support narrower than 1e-3 and of cells whose profile does not peak at zero."""
+    from godot_amd import core
+    g = golden('cells_sparse.npz')
+    d = _dev()
+    n = 60
+    off = np.append(0, np.cumsum(g['counts'])).astype(np.int64)
+    offd = torch.from_numpy(off).to(d)
+    sexp = torch.from_numpy(g['exp']).to(d)
+    bexp = torch.from_numpy(g['exp'] / g['SonB']).to(d)
+    batch = core.CellBatch(torch.from_numpy(g['we']).to(d), torch.from_numpy(g['we']).to(d),
+                           offd[:-1][:n].contiguous(), offd[1:][:n].contiguous(),
+                           torch.from_numpy(g['starts'][:n].copy()).to(d),
+                           torch.from_numpy(g['stops'][:n].copy()).to(d), sexp[:n].contiguous(),
+                           bexp[:n].contiguous())
+    cll = core.CellsLogLikelihood(batch)
+    bad_x, bad_y = cll.sanity_check()
+    dom, cod = cll._dom, cll._cod
+    assert np.array_equal(bad_x, np.ravel(np.argwhere(np.abs(dom[:, -1] - dom[:, 0]) < 1e-3)))
+    assert np.array_equal(bad_y, np.ravel(np.argwhere(np.abs(cod.max(axis=1)) > 0.2)))
+    out = capsys.readouterr().out
+    assert 'suspiciously narrow support' in out and 'substantial disagreement' in out
+    # a profile that peaks away from zero and a degenerate support are reported
+    cll._cod_h = cod.copy()
+    cll._cod_h[7] -= 1.0
+    cll._dom_h = dom.copy()
+    cll._dom_h[11] = dom[11, 0]
+    bad_x, bad_y = cll.sanity_check()
+    assert 11 in bad_x and 7 in bad_y
+
+
+def test_profile_background_with_swap_zeroes_ts_where_the_swapped_exposure_vanishes():
+    """get_ts looks at the exposure the swapped likelihood calls S, which is the background
+    exposure (reference core.py:343-345, 982-984): a cell without background exposure gets
+    TS = 0 under swap, one without source exposure does not."""
+    from godot_amd import core
+    d = _dev()
+    rng = np.random.default_rng(3)
+    cnt = np.array([30, 25, 28, 31])
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.6, 1.2, int(off[-1])), 1e-3, 1 - 1e-3)
+    sexp = np.array([6.0, 5.0, 5.5, 6.2])
+    bexp = np.array([22.0, 0.0, 20.0, 21.0])      # cell 1: no background exposure
+    offd = torch.from_numpy(off).to(d)
+    wd = torch.from_numpy(we).to(d)
+    batch = core.CellBatch(wd, wd, offd[:-1].contiguous(), offd[1:].contiguous(),
+                           torch.arange(4, dtype=torch.float64, device=d) * 600. + 3e8,
+                           torch.arange(1, 5, dtype=torch.float64, device=d) * 600. + 3e8,
+                           torch.from_numpy(sexp).to(d), torch.from_numpy(bexp).to(d))
+    cll = core.CellsLogLikelihood.__new__(core.CellsLogLikelihood)
+    cll.cells = batch
+    cll._swap = True
+    cll.profile_background = True
+    cll.allow_failed_cells = False
+    cll._cr = batch.ranges()
+    dom = torch.linspace(0.0, 3.0, 50, dtype=torch.float64, device=d).repeat(4, 1).contiguous()
+    cod = (-(dom - 1.0) ** 2).contiguous()
+    cll._dom_d, cll._cod_d, cll._dom_h, cll._cod_h = dom, cod, None, None
+    aopt, ts, _, _ = cll.get_flux_all()
+    ts = ts.cpu().numpy()
+    assert ts[1] == 0.0 and (ts[[0, 2, 3]] != 0.0).all()
+
+
 def test_small_per_cell_functions_match_reference(golden):
     """log_full_likelihood, fmin_tnc_func, f1/f2/f3, f1_profile,
     log_profile_likelihood_approx, nr, halley, the bracketing maxima and

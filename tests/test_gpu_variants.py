@@ -48,6 +48,26 @@ def test_scaler_values_match_reference(golden):
     assert np.array_equal(src(g['in_ti']), g['scaler_events'])
     on_dev = src(torch.from_numpy(g['in_ti']).to(DEV)).cpu().numpy()
     assert np.array_equal(on_dev, g['scaler_events'])
+    # averages over the rows of the spacecraft table, on the device: the same bits
+    rows = src(torch.from_numpy(g['in_TSTART']).to(DEV), torch.from_numpy(g['in_TSTOP']).to(DEV))
+    assert rows.is_cuda and np.array_equal(rows.cpu().numpy(), g['scaler_rows'])
+
+
+def test_scaler_averages_on_the_device_equal_the_host_arithmetic():
+    """Intervals inside one segment, across one boundary, across many, beginning exactly on
+    a boundary, before the first and behind the last segment: host and device agree bit for bit."""
+    from godot_amd.scalers import PiecewiseScaler
+    rng = np.random.default_rng(21)
+    edges = np.cumsum(rng.uniform(50., 5000., 41)) + 1e8
+    sc = PiecewiseScaler(edges[:-1], edges[1:], rng.uniform(0.2, 5.0, 40))
+    t0 = rng.uniform(edges[0] - 5e3, edges[-1] + 5e3, 20000)
+    t1 = t0 + rng.choice([30., 300., 3000., 30000.], 20000) * rng.uniform(0.1, 1.0, 20000)
+    t0[:40] = edges[:40]                      # starts on the boundaries themselves
+    t1[:40] = edges[:40] + rng.uniform(1., 9000., 40)
+    host = sc(t0, t1)
+    dev = sc(torch.from_numpy(t0).to(DEV), torch.from_numpy(t1).to(DEV)).cpu().numpy()
+    assert np.array_equal(host, dev)
+    assert (host != sc(t0)).any()             # some intervals did span segments
 
 
 def test_scaled_cells_match_reference(golden):
