@@ -65,6 +65,8 @@ SIGNATURES = {
     'godot_cell_moments': (c_int, _CELLS + [c_i64, c_f64p, c_f64p, c_stream]),
     'godot_select_workspace_bytes': (c_size, [c_i64]),
     'godot_select_cells': (c_int, [c_f64p, c_i64, c_f64, c_i64p, c_i64p, c_ws, c_size, c_stream]),
+    'godot_select_cells_static_max': (c_i64, []),
+    'godot_select_cells_static': (c_int, [c_f64p, c_i64, c_f64, c_i64p, c_i64p, c_stream]),
     'godot_gather_f64': (c_int, [c_f64p, c_i64p, c_i64, c_f64p, c_stream]),
     'godot_gather_i64': (c_int, [c_i64p, c_i64p, c_i64, c_i64p, c_stream]),
     'godot_rfft_workspace_bytes': (c_size, [c_i64]),

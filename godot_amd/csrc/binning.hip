@@ -6,6 +6,7 @@
 // and one deliberately serial pass (the exposure running sums, see below).
 #include "common.hpp"
 #include <type_traits>
+#include <mutex>
 
 namespace {
 
@@ -1058,6 +1059,83 @@ extern "C" int godot_select_cells(const double *exp, int64_t ncell, double thres
                        dim3(SCAN_THREADS), 0, st, ld, ncell, (const int64_t *)part,
                        SelectStore{exp, threshold, keep_idx});
     GODOT_LAUNCH_CHECK("godot_select_cells");
+    return GODOT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// godot_select_cells for callers that cannot allocate: the tile counts of the
+// scan live in a file-scope device array instead of a caller's workspace.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int64_t SELECT_STATIC_MAX_TILES = 8192;     // tiles of SCAN_TILE = 2048 cells: 16 777 216 cells
+constexpr int SELECT_STATIC_MAX_DEVICES = 64;
+
+// 64 KB on every GPU the library runs on, until the process ends.  Each GPU holds its own
+// copy at its own address; `scratch` itself is only the host-side handle of the symbol.
+static __device__ __align__(256) int64_t scratch[SELECT_STATIC_MAX_TILES + 1];
+
+// Device address of `scratch` on the current GPU, looked up once per device.
+int select_static_scratch(int64_t **out)
+{
+    static std::mutex mu;
+    static int64_t *addr[SELECT_STATIC_MAX_DEVICES] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        godot_set_error("godot_select_cells_static: hipGetDevice: %s", hipGetErrorString(e));
+        return GODOT_E_LAUNCH;
+    }
+    GODOT_REQUIRE(dev >= 0 && dev < SELECT_STATIC_MAX_DEVICES, GODOT_E_UNSUPPORTED,
+                  "godot_select_cells_static: device index %d beyond %d", dev, SELECT_STATIC_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!addr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            godot_set_error("godot_select_cells_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return GODOT_E_LAUNCH;
+        }
+        addr[dev] = (int64_t *)p;
+    }
+    *out = addr[dev];
+    return GODOT_OK;
+}
+
+}   // namespace
+
+extern "C" int64_t godot_select_cells_static_max(void) { return SELECT_STATIC_MAX_TILES * SCAN_TILE; }
+
+extern "C" int godot_select_cells_static(const double *exp, int64_t ncell, double threshold, int64_t *keep_idx,
+                                         int64_t *n_keep, godot_stream_t stream)
+{
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_select_cells_static: negative ncell");
+    GODOT_REQUIRE(ncell <= SELECT_STATIC_MAX_TILES * SCAN_TILE, GODOT_E_UNSUPPORTED,
+                  "godot_select_cells_static: %lld cells, the built-in scratch holds the counts of at most %lld "
+                  "(use godot_select_cells with a workspace)", (long long)ncell,
+                  (long long)(SELECT_STATIC_MAX_TILES * SCAN_TILE));
+    GODOT_REQUIRE(n_keep, GODOT_E_INVALID, "godot_select_cells_static: null n_keep");
+    hipStream_t st = (hipStream_t)stream;
+    if (ncell == 0) {
+        (void)hipMemsetAsync(n_keep, 0, sizeof(int64_t), st);
+        return GODOT_OK;
+    }
+    GODOT_REQUIRE(exp && keep_idx, GODOT_E_INVALID, "godot_select_cells_static: null argument");
+    int64_t *part = nullptr;
+    int rc = select_static_scratch(&part);
+    if (rc) return rc;
+    // every entry the scan reads is written by the reduction before it: nothing has to
+    // start at zero, whatever an earlier (larger) call left behind
+    int64_t ntiles = ceil_div(ncell, SCAN_TILE);
+    MaskLoad ld{exp, threshold};
+    hipLaunchKernelGGL((tile_reduce_kernel<int64_t, MaskLoad>), dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0,
+                       st, ld, ncell, part);
+    hipLaunchKernelGGL((scan_partials_kernel<int64_t>), dim3(1), dim3(SCAN_THREADS), 0, st, part, ntiles,
+                       n_keep);
+    hipLaunchKernelGGL((tile_scan_kernel<int64_t, MaskLoad, SelectStore>), dim3((unsigned)ntiles),
+                       dim3(SCAN_THREADS), 0, st, ld, ncell, (const int64_t *)part,
+                       SelectStore{exp, threshold, keep_idx});
+    GODOT_LAUNCH_CHECK("godot_select_cells_static");
     return GODOT_OK;
 }
 

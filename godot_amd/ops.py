@@ -383,6 +383,19 @@ def select_cells(exp, threshold=0.0):
     return keep[:int(nk.item())]
 
 
+def select_cells_static(exp, threshold, keep, n_keep):
+    """select_cells into the caller's tensors, through the entry point that allocates
+    nothing (keep: int64 [>= exp.numel()], n_keep: int64 [1]); nothing is synchronised."""
+    _dev_check(exp, F64, 'exp')
+    _dev_check(keep, I64, 'keep')
+    _dev_check(n_keep, I64, 'n_keep')
+    if keep.numel() < exp.numel() or n_keep.numel() < 1:
+        raise ValueError('keep must hold one index per cell and n_keep one count')
+    with torch.cuda.device(exp.device):
+        _lib.call('godot_select_cells_static', _p(exp), exp.numel(), float(threshold), _p(keep), _p(n_keep),
+                  _stream(exp.device))
+
+
 def gather(src, idx):
     _dev_check(idx, I64, 'idx')
     n, dev = idx.numel(), src.device

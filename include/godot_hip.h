@@ -286,6 +286,19 @@ int godot_select_cells(const double *exp, int64_t ncell, double threshold,
                        int64_t *keep_idx, int64_t *n_keep,
                        void *workspace, size_t workspace_bytes,
                        godot_stream_t stream);
+/* godot_select_cells without a workspace.  No counterpart in the reference: it
+ * is for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  The tile
+ * counts of the scan live in a 64 KB file-scope device array that every GPU the
+ * library runs on holds until the process ends; ncell is limited to
+ * godot_select_cells_static_max() = 16 777 216 (GODOT_E_UNSUPPORTED beyond).
+ * Same outputs as godot_select_cells, bit for bit.  The call allocates and
+ * frees nothing.  All calls on one GPU share that array: calls that overlap in
+ * time on one GPU (two streams, two threads) race; calls on one stream do not.  */
+int64_t godot_select_cells_static_max(void);
+int godot_select_cells_static(const double *exp, int64_t ncell, double threshold,
+                              int64_t *keep_idx, int64_t *n_keep,
+                              godot_stream_t stream);
 int godot_gather_f64(const double *src, const int64_t *idx, int64_t n,
                      double *dst, godot_stream_t stream);
 int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n,
