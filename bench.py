@@ -2,30 +2,40 @@
 """Benchmark of the weighted-photon likelihood hot path on MI355X.
 
 One "step" = one batched maximum-likelihood fit (alpha-hat + TS, the
-reference's get_max + get_ts) of every cell of the workload
+reference's get_max + get_ts) of every cell of one photon list of the workload
     C2: 1e7 synthetic photons, 10 yr, 10-minute cells (zero-exposure cells
         trimmed), cells built by the GPU binning path,
-with all inputs resident in HBM.  Weak scaling: every rank owns one such
-photon list (seed 11 + rank) and fits its own cells: the path has no exchange
-between ranks, so the timed steps hold no collective.  The per-cell records of
-all ranks are gathered once over RCCL after the timed region (its time is
-reported as extra.gather_ms).  Rank 0 prints one JSON line.
+with all inputs resident in HBM.  Every rank owns NLIST = 4 such lists (seeds
+11 + 4 rank + j) and the steps go round them, so that 376 MB of other inputs
+pass between two fits of the same list: more than the 256 MiB Infinity Cache
+holds, the weights come from HBM.  Weak scaling: the path has no exchange
+between ranks, so the timed steps hold no collective; value = cells fitted per
+second by all ranks.
 
-Also reported (rank 0, "extra"): the 200-point profile-grid rate on the same
-cells, the Z^2_2 search rate (photon x frequency evaluations per second), the
-power_spectrum_fft time at the C3 size (3 786 912 bins -> l = 2^25), the
-one-off binning time, and the CPU baseline: the numpy oracle (a restatement
-of the reference's per-cell Python path) timed on one host core on a bounded
-sample of the same cells.
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N
+ranks itself (fresh child processes, before this process touches a GPU).
+
+Also reported (rank 0, "extra"):
+  * strong scaling of the two sharded jobs, collectives inside the timed
+    region: C2's cells of ONE list split over the ranks by photon count, the
+    per-cell records all-gathered every step; C4 (1e6 photons x 1e8 trial
+    frequencies, m = 2) with the frequencies split over the ranks and the global
+    top ten gathered;
+  * the same fit on one list kept in the cache, the 200-point profile grid,
+    dense cells, power_spectrum_fft at the C3 size, binning, Bayesian Blocks;
+  * CPU baselines: the numpy oracle (a restatement of the reference's Python
+    path) on one core and on all cores of the box, for the cell fit, the Z^2_2
+    sums and the FFT power spectrum.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -33,6 +43,11 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 peak
+NLIST = 4                  # photon lists a rank rotates through
+# hardware-counted FP64 work of the Z^2_2 kernel per (photon, frequency) evaluation:
+# profiles/r2_z2m_flops.json (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 passes on the timed kernel)
+Z2M_FLOP_FILE = os.path.join(REPO, 'profiles', 'r2_z2m_flops.json')
+FIT_TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r2_cell_fit_traffic.json')
 
 
 def parse():
@@ -43,24 +58,38 @@ def parse():
     ap.add_argument('--nph', type=int, default=10_000_000)
     ap.add_argument('--years', type=float, default=10.0)
     ap.add_argument('--tcell', type=float, default=600.0)
+    ap.add_argument('--nfreq', type=int, default=100_000_000, help='trial frequencies of the C4 search')
     ap.add_argument('--no-extra', action='store_true', help='skip the extra measurements')
-    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baselines')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
 
 
-def event_time_ms(fn, iters, stream):
-    """Average device time of fn() over iters launches, HIP events on `stream`."""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(iters)]
-    for a, b in evs:
-        a.record(stream)
-        fn()
-        b.record(stream)
-    torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+# ---------------------------------------------------------------------------
+# launching the ranks
+# ---------------------------------------------------------------------------
+def spawn_ranks(n):
+    """Start n ranks of this script as child processes (this process has not touched a
+    GPU and never will) and pass on rank 0's JSON line, which goes to the shared stdout."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    sys.exit(rc)
 
 
+# ---------------------------------------------------------------------------
+# CPU baselines (the oracle; run before the process initialises the GPU)
+# ---------------------------------------------------------------------------
 def _cpu_sample(s, tcell):
     """Arrays of a leading slice (40 days) of the workload, small enough to hand to worker processes."""
     t_end = s['TSTART'][0] + 40 * 86400.
@@ -71,7 +100,7 @@ def _cpu_sample(s, tcell):
                 tcell=tcell)
 
 
-def _cpu_worker(p, seconds):
+def _cpu_fit_worker(p, seconds):
     """The oracle's per-cell get_max + get_ts over the sample, repeated for `seconds`: (cells, time, ncell)."""
     from oracle import godot_oracle as orc
     # binning itself is not timed
@@ -91,31 +120,96 @@ def _cpu_worker(p, seconds):
     return n, time.perf_counter() - t0, len(clls)
 
 
-def cpu_baseline(s, tcell, seconds):
+def _cpu_z2m_worker(p, seconds):
+    """The oracle's Z^2_2 over blocks of 16 trial frequencies for `seconds`: (evaluations, time)."""
+    from oracle import godot_oracle as orc
+    n = 0
+    j0 = p['j0']
+    t0 = time.perf_counter()
+    while True:
+        orc.z2m(p['t'], p['w'], p['f0'], p['df'], 16, m=2, j0=j0)
+        j0 += 16
+        n += 16 * len(p['t'])
+        if time.perf_counter() - t0 > seconds:
+            break
+    return n, time.perf_counter() - t0
+
+
+def _cpu_fft_worker(p, _seconds):
+    """One power_spectrum_fft of the oracle (five numpy rfft of length l and the estimators): (1, time)."""
+    from oracle import godot_oracle as orc
+    nb = p['nbins']
+    rng = np.random.default_rng(13)
+    cnt = rng.poisson(2.6, nb).astype(float)
+    W, WW = cnt * 0.17, cnt * 0.08
+    S = np.full(nb, 0.44)
+    starts = 100. * np.arange(nb)
+    t0 = time.perf_counter()
+    out = orc.power_spectrum_fft(starts, starts + 100., cnt, W, WW, S, S * 5)
+    return 1, time.perf_counter() - t0, 4 * (len(out[0]) - 1)
+
+
+def _all_cores(fn, p, seconds, cores):
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(cores, mp_context=mp.get_context('spawn')) as ex:
+        return list(ex.map(fn, [p] * cores, [seconds] * cores))
+
+
+def cpu_baselines(s, args):
     """The oracle on the host cores: one core (the reference is single-threaded), then the
     same loop in one process per core.  Must run before this process touches the GPU: the
     workers are spawned."""
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
-    p = _cpu_sample(s, tcell)
-    n, dt, ncl = _cpu_worker(p, seconds)
-    out = dict(value=n / dt, unit='cells/s', cores=1, kind='port',
+    from godot_amd import synth
+    cores = max(1, min(16, os.cpu_count() or 1))
+    sec = args.cpu_seconds
+    p = _cpu_sample(s, args.tcell)
+    n, dt, ncl = _cpu_fit_worker(p, sec)
+    fit = dict(value=n / dt, unit='cells/s', cores=1, kind='port',
                sample='oracle get_max+get_ts over the first %d cells (40 days) of the same '
                       'workload, repeated for %.0f s on one core' % (ncl, dt))
-    cores = max(1, min(16, os.cpu_count() or 1))
     try:
-        with ProcessPoolExecutor(cores, mp_context=mp.get_context('spawn')) as ex:
-            res = list(ex.map(_cpu_worker, [p] * cores, [seconds / 2] * cores))
-        out['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), unit='cells/s',
-                                cores=cores,
-                                sample='the same loop in %d processes, %.0f s each' % (cores, seconds / 2))
+        res = _all_cores(_cpu_fit_worker, p, sec / 2, cores)
+        fit['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), unit='cells/s', cores=cores,
+                                sample='the same loop in %d processes, %.0f s each' % (cores, sec / 2))
     except Exception as e:   # a box that cannot spawn workers still reports the one-core figure
-        out['all_cores'] = dict(value=None, error=repr(e))
-    return out
+        fit['all_cores'] = dict(value=None, error=repr(e))
+    if args.no_extra:
+        return fit, None
+    other = {}
+    # Z^2_2: the C4 photon list, a few blocks of trial frequencies
+    zs = synth.synth(1_000_000, years=1.0, seed=17)
+    zt = zs['ti'] - zs['ti'][0]
+    zp = dict(t=zt, w=zs['we'], f0=1e-4, df=1.0 / (4 * float(zt[-1])), j0=0)
+    n, dt = _cpu_z2m_worker(zp, sec / 2)
+    z = dict(value=n / dt, unit='photon x frequency evaluations/s', cores=1, kind='port',
+             sample='oracle z2m (m = 2) on the C4 photon list, blocks of 16 trial frequencies for %.0f s' % dt)
+    try:
+        res = _all_cores(_cpu_z2m_worker, zp, sec / 3, cores)
+        z['all_cores'] = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores,
+                              unit='photon x frequency evaluations/s')
+    except Exception as e:
+        z['all_cores'] = dict(value=None, error=repr(e))
+    other['z2m'] = z
+    # FFT power spectrum one size below C3 (l = 2^24: a 2^25 run takes twice as long and as much again in memory)
+    fp = dict(nbins=1_893_456)
+    _, dt, l = _cpu_fft_worker(fp, 0)
+    f = dict(value=dt, unit='s per power_spectrum_fft', cores=1, kind='port', l=l, nbins=fp['nbins'],
+             sample='oracle power_spectrum_fft (five numpy rfft of length 2^24 + estimators), once')
+    try:
+        res = _all_cores(_cpu_fft_worker, fp, 0, min(cores, 8))
+        f['all_cores'] = dict(value=max(r[1] for r in res) / len(res), cores=min(cores, 8),
+                              unit='s per power_spectrum_fft (one spectrum per process, all at once)')
+    except Exception as e:
+        f['all_cores'] = dict(value=None, error=repr(e))
+    other['power_spectrum_fft'] = f
+    return fit, other
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------
+def run_rank(args):
     # Libraries write to stdout as well (RCCL prints a version banner when it starts):
     # file descriptor 1 points to stderr until the one JSON line is due.
     sys.stdout.flush()
@@ -124,120 +218,204 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    from godot_amd import synth
+
+    # ---- workload: C2, NLIST photon lists per rank; CPU comparators first, while this
+    # process has not initialised the GPU (they spawn workers)
+    lists = [synth.synth(args.nph, years=args.years, seed=11 + NLIST * rank + j) for j in range(NLIST)]
+    cpu = cpu_other = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu, cpu_other = cpu_baselines(lists[0], args)
+
+    import torch
     dist = None
-    # GODOT_BENCH_FORCE_DIST=1: take the multi-rank path with a single rank too (a rehearsal
-    # of the collectives on a one-GPU box)
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(ndev, 1)
+    # GODOT_BENCH_BACKEND=gloo: a rehearsal of the multi-rank path on a box with fewer GPUs
+    # than ranks (RCCL wants a GPU per rank); GODOT_BENCH_FORCE_DIST=1: the multi-rank code
+    # with a single rank
+    backend = os.environ.get('GODOT_BENCH_BACKEND', 'nccl')
     if world > 1 or os.environ.get('GODOT_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
-    from godot_amd import core, ops, synth
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    from godot_amd import core, ops
+    from godot_amd import dist as gd
 
-    # ---- workload: C2, one photon list per rank ---------------------------------
-    s = synth.synth(args.nph, years=args.years, seed=11 + rank)
-    # CPU comparator first, while this process has not initialised the GPU (it spawns workers)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(s, args.tcell, args.cpu_seconds)
-
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')     # where collectives take their tensors
     stream = torch.cuda.current_stream(dev)
-    data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'],
-                     device=dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
-    torch.cuda.synchronize()
-    t_bin_first = time.perf_counter() - t0
-    # with the running sums of the exposure table cached: mean of five calls
-    t0 = time.perf_counter()
-    for _ in range(5):
-        cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
-    torch.cuda.synchronize()
-    t_bin_again = (time.perf_counter() - t0) / 5
-    cr = cells.ranges()
-    ncell = cr.ncell
-    nph_in = int((cr.hi - cr.lo).sum().cpu())
 
-    def step():
-        return ops.cell_fit(cr)
-
-    for _ in range(args.warmup):
-        step()
+    def event_time_ms(fn, iters):
+        """Average device time of fn(i) over iters launches, HIP events on the launch stream."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i, (a, b) in enumerate(evs):
+            a.record(stream)
+            fn(i)
+            b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].cpu())
+
+    crs = []
+    t_bin_first = t_bin_again = None
+    data0 = None
+    for j, s in enumerate(lists):
+        data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+        torch.cuda.synchronize()
+        if j == 0:
+            t_bin_first = time.perf_counter() - t0
+            # with the running sums of the exposure table cached: mean of five calls
+            t0 = time.perf_counter()
+            for _ in range(5):
+                cells = data.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+            torch.cuda.synchronize()
+            t_bin_again = (time.perf_counter() - t0) / 5
+            data0 = data
+        crs.append(cells.ranges())
+        del data, cells
+    lists = lists[:1]
+    torch.cuda.empty_cache()
+    ncells = [cr.ncell for cr in crs]
+    nphs = [int((cr.hi - cr.lo).sum().cpu()) for cr in crs]
+
+    def step(i):
+        return ops.cell_fit(crs[i % NLIST])
+
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    cells_done = float(sum(ncells[i % NLIST] for i in range(args.steps)))
 
-    tot = torch.tensor([elapsed, float(ncell)], dtype=torch.float64, device=dev)
     if dist is not None:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([cells_done], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0].cpu())
-    total_cells = float(tot[1].cpu())
+        cells_done = float(tot[0].cpu())
+    elapsed = max_over_ranks(elapsed)
 
-    # The job's epilogue, outside the timed steps (the path has no exchange between ranks:
-    # each fits its own cells): per-cell (alpha, TS) records of all ranks gathered once.
-    gather_ms = None
-    if dist is not None:
-        t0 = time.perf_counter()
-        rec = torch.stack([out[0], out[1]], dim=1)
-        nmax = torch.tensor([ncell], device=dev)
-        dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-        pad = torch.zeros((int(nmax.item()), 2), dtype=rec.dtype, device=dev)
-        pad[:ncell] = rec
-        gathered = torch.empty((world,) + tuple(pad.shape), dtype=rec.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, pad)
+    extra = dict(ncell_per_list=ncells, photons_in_cells_per_list=nphs, lists_per_rank=NLIST,
+                 binning_first_call_s=t_bin_first, binning_cached_table_s=t_bin_again)
+
+    # ---- strong scaling, collectives inside the timed region -----------------------
+    if not args.no_extra:
+        # (1) the cells of ONE photon list (seed 11 on every rank) split by photon count; every
+        # step fits the rank's shard and all-gathers the (alpha, TS) records of all cells
+        if rank == 0:
+            cr_all = crs[0]
+        else:
+            s0 = synth.synth(args.nph, years=args.years, seed=11)
+            d0 = core.Data(s0['ti'], s0['we'], s0['TSTART'], s0['TSTOP'], s0['LIVETIME'], s0['exposure'], device=dev)
+            cr_all = d0.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True).ranges()
+            del s0, d0
+        counts = (cr_all.hi - cr_all.lo).cpu().numpy()
+        c0, c1 = gd.cell_shard(counts, rank, world)
+        mine = cr_all.shard(c0, c1)
+        sizes = [gd.cell_shard(counts, r, world)[1] - gd.cell_shard(counts, r, world)[0] for r in range(world)]
+
+        def strong_step():
+            a, t, _ = ops.cell_fit(mine)
+            rec = torch.stack([a, t], dim=1)
+            return gd.all_gather_ragged(rec.to(cdev), sizes=sizes)
+
+        for _ in range(5):
+            rec = strong_step()
+        nstrong = max(10, args.steps // 4)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        del gathered, pad, rec
-
-    # ---- the second half of the metric across the ranks: one Z^2_2 search, trial
-    # frequencies sharded (2^21 per rank), photons replicated, global maximum gathered
-    z2_all = None
-    if dist is not None and not args.no_extra:
-        from godot_amd import dist as gd
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nstrong):
+            rec = strong_step()
+        torch.cuda.synchronize()
+        barrier()
+        t_strong = max_over_ranks(time.perf_counter() - t0) / nstrong
+        extra['strong_c2_fit'] = dict(cells_per_s=len(counts) / t_strong, ms_per_step=t_strong * 1e3,
+                                      ncell=int(len(counts)), n_gpus=world, records_gathered=int(rec.shape[0]),
+                                      cells_on_rank0=int(c1 - c0),
+                                      sharding='cells split by photon count (dist.cell_shard), (alpha, TS) '
+                                               'records all-gathered inside every timed step')
+        del rec, mine
+        # (2) C4: 1e6 photons x nfreq trial frequencies, m = 2, frequencies split over the ranks,
+        # global top ten gathered; the search runs in launches of 2^21 frequencies
         zs = synth.synth(1_000_000, years=1.0, seed=17)
         zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
         zw = torch.from_numpy(zs['we']).to(dev)
-        nf_all = (1 << 21) * world
         zspan = float(zs['ti'][-1] - zs['ti'][0])
         zf0, zdf = 1e-4, 1.0 / (4 * zspan)
-        zws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), 1 << 21, 2), dtype=torch.uint8,
+        chunk = 1 << 21
+        zws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), chunk, 2), dtype=torch.uint8,
                           device=dev)
+        kernel_ms = []
+        j0_mine, n_mine = gd.frequency_shard(args.nfreq, rank, world)
+        zbuf = torch.empty(n_mine, dtype=torch.float64, device=dev)
 
         def search_fn(j0, n):
-            return ops.z2m(zt, zw, zf0, zdf, n, m=2, j0=j0, workspace=zws)[0]
+            """The statistic on this rank's slice, launch by launch, into one buffer."""
+            for k0 in range(0, n, chunk):
+                nn = min(chunk, n - k0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                zbuf[k0:k0 + nn] = ops.z2m(zt, zw, zf0, zdf, nn, m=2, j0=j0 + k0, workspace=zws)[0]
+                e1.record(stream)
+                kernel_ms.append((e0, e1, nn))
+            return zbuf[:n]
 
-        gd.search_sharded(nf_all, search_fn)
+        def topk_sharded():
+            return gd.search_topk_sharded(args.nfreq, search_fn, k=10)
+
+        ops.z2m(zt, zw, zf0, zdf, chunk, m=2, workspace=zws)        # warm-up launch
         torch.cuda.synchronize()
+        kernel_ms.clear()
         barrier()
         t0 = time.perf_counter()
-        zmax, jmax, _ = gd.search_sharded(nf_all, search_fn)
+        top_v, top_i = topk_sharded()
         torch.cuda.synchronize()
         barrier()
-        zt_s = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(zt_s, op=dist.ReduceOp.MAX)
-        z_s = float(zt_s[0].cpu())
-        z2_all = dict(photon_freq_evals_per_s=float(zt.numel()) * nf_all / z_s, s=z_s, nph=zt.numel(),
-                      nfreq=nf_all, m=2, n_gpus=world, z2_max=zmax, argmax=jmax,
-                      sharding='frequencies; photons replicated; all-gather of per-rank maxima')
-        del zws
+        z_s = max_over_ranks(time.perf_counter() - t0)
+        k_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_ms)
+        k_n = sum(nn for _, _, nn in kernel_ms)
+        evals = float(zt.numel()) * args.nfreq / z_s
+        zrec = dict(photon_freq_evals_per_s=evals, s=z_s, nph=zt.numel(), nfreq=args.nfreq, m=2, n_gpus=world,
+                    z2_max=float(top_v[0]), argmax=int(top_i[0]),
+                    kernel_evals_per_s_rank0=float(zt.numel()) * k_n / (k_ms * 1e-3),
+                    sharding='frequencies split (dist.frequency_shard), photons replicated, per-rank top ten '
+                             'all-gathered')
+        if os.path.exists(Z2M_FLOP_FILE):
+            with open(Z2M_FLOP_FILE) as f:
+                zf = json.load(f)
+            fpe = zf.get('fp64_flop_per_evaluation')
+            if fpe:
+                zrec['hardware_counted_fp64_flop_per_eval'] = fpe
+                zrec['executed_frac_of_fp64_peak'] = fpe * evals / (FP64_PEAK_TFLOPS * 1e12 * world)
+        extra['strong_c4_z2m'] = zrec
+        del zws, zt, zw, zbuf
         torch.cuda.empty_cache()
 
     if rank != 0:
@@ -247,60 +425,48 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (cell_fit), HIP events on its stream -----
-    k_ms = event_time_ms(step, max(20, min(args.steps, 200)), stream)
-    alg_bytes = 8 * nph_in + 8 * (ncell + 1) + 16 * ncell + 16 * ncell
+    nev = max(20, min(args.steps, 200))
+    k_ms = event_time_ms(step, nev)
+    alg = [8 * nphs[j] + 8 * (ncells[j] + 1) + 16 * ncells[j] + 16 * ncells[j] for j in range(NLIST)]
+    alg_bytes = float(np.mean([alg[i % NLIST] for i in range(nev)]))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # the same fit on one list every time: its 98 MB stay in the 256 MiB Infinity Cache
+    r_ms = event_time_ms(lambda i: ops.cell_fit(crs[0]), nev)
     # HBM bytes per launch from the PMC passes (taken separately with rocprofv3 on this same
-    # workload and committed under profiles/; null when the workload differs from the one profiled)
+    # rotating workload and committed under profiles/; null when the workload differs)
     traffic = None
-    tpath = os.path.join(REPO, 'profiles', 'r1_cell_fit_traffic.json')
-    if os.path.exists(tpath) and args.nph == 10_000_000 and args.tcell == 600.0 and args.years == 10.0:
-        with open(tpath) as f:
-            traffic = json.load(f).get('traffic_bytes_per_launch')
+    kernel_name = 'cell_fit_group_b0_kernel<2, 20, true>'
+    if os.path.exists(FIT_TRAFFIC_FILE) and args.nph == 10_000_000 and args.tcell == 600.0 and args.years == 10.0:
+        with open(FIT_TRAFFIC_FILE) as f:
+            tj = json.load(f)
+        traffic = tj.get('traffic_bytes_per_launch')
+        kernel_name = tj.get('kernel', kernel_name)
     roofline = dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, kernel='cell_fit_group_b0_kernel<2, 16, true>',
-                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=k_ms)
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, kernel=kernel_name,
+                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=k_ms,
+                    inputs='%d photon lists in rotation (%.0f MB between two fits of one list)' % (
+                        NLIST, sum(alg) / 1e6 - alg[0] / 1e6),
+                    cache_resident=dict(avg_launch_ms=r_ms, achieved=alg[0] / (r_ms * 1e-3) / 1e9,
+                                        frac=alg[0] / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        inputs='one list fitted over and over (98 MB: stays in the Infinity Cache)'))
 
-    extra = dict(ncell=ncell, photons_in_cells=nph_in,
-                 binning_first_call_s=t_bin_first, binning_cached_table_s=t_bin_again)
-    if z2_all is not None:
-        extra['z2m_all_gpus'] = z2_all
-    if gather_ms is not None:
-        extra['gather_ms'] = gather_ms
     if not args.no_extra:
+        cr = crs[0]
+        ncell, nph_in = ncells[0], nphs[0]
         # 200-point profile grid on the same cells (FP64-ALU bound)
         ops.cell_logpdf(cr, dlogl=30, npt=200)
-        p_ms = event_time_ms(lambda: ops.cell_logpdf(cr, dlogl=30, npt=200), 5, stream)
+        p_ms = event_time_ms(lambda i: ops.cell_logpdf(cr, dlogl=30, npt=200), 5)
         extra['profile_grid'] = dict(cells_per_s=ncell / (p_ms * 1e-3), ms=p_ms,
                                      log_evals_per_s=200.0 * nph_in / (p_ms * 1e-3))
         torch.cuda.empty_cache()
         # dense cells (the per-source shape of C1 / C5): same photons in 2-hour cells
-        dcells = data.get_cells(tcell=7200., use_barycenter=False, quiet=True)
-        dcr = dcells.ranges()
+        dcr = data0.get_cells(tcell=7200., use_barycenter=False, quiet=True).ranges()
         ops.cell_fit(dcr)
-        d_ms = event_time_ms(lambda: ops.cell_fit(dcr), 20, stream)
+        d_ms = event_time_ms(lambda i: ops.cell_fit(dcr), 20)
         dn = int((dcr.hi - dcr.lo).sum().cpu())
         extra['dense_cells'] = dict(ncell=dcr.ncell, photons_per_cell=dn / max(dcr.ncell, 1), ms=d_ms,
                                     cells_per_s=dcr.ncell / (d_ms * 1e-3),
                                     algorithmic_GBps=(8 * dn + 40 * dcr.ncell) / (d_ms * 1e-3) / 1e9)
-        # Z^2_2 search: 1e6 photons x 2^21 trial frequencies (a slice of C4's 1e8)
-        zs = synth.synth(1_000_000, years=1.0, seed=17)
-        zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
-        zw = torch.from_numpy(zs['we']).to(dev)
-        nf = 1 << 21
-        span = float(zs['ti'][-1] - zs['ti'][0])
-        f0, df = 1e-4, 1.0 / (4 * span)
-        ws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), nf, 2), dtype=torch.uint8,
-                         device=dev)
-        ops.z2m(zt, zw, f0, df, nf, m=2, workspace=ws)
-        z_ms = event_time_ms(lambda: ops.z2m(zt, zw, f0, df, nf, m=2, workspace=ws), 3, stream)
-        evals = float(zt.numel()) * nf / (z_ms * 1e-3)
-        extra['z2m'] = dict(photon_freq_evals_per_s=evals, ms=z_ms, nph=zt.numel(), nfreq=nf, m=2,
-                            nominal_flops_per_eval=45, executed_valu_instr_per_eval=9.4,
-                            nominal_frac_of_fp64_peak=45 * evals / (FP64_PEAK_TFLOPS * 1e12),
-                            executed_frac_of_fp64_issue=2 * 9.4 * evals / (FP64_PEAK_TFLOPS * 1e12))
-        del ws
-        torch.cuda.empty_cache()
         # power_spectrum_fft at the C3 size: 3 786 912 bins of 100 s -> l = 2^25
         nb = 3_786_912
         g = torch.Generator(device=dev)
@@ -311,14 +477,16 @@ def main():
         S = torch.full((nb,), 0.44, dtype=torch.float64, device=dev)
         B = S * 5
         l = 1 << 25
-        ops.power_spectrum_fft(W, WW, S, cnt - W, cnt - 2 * W + WW, B, l)
-        f_ms = event_time_ms(lambda: ops.power_spectrum_fft(W, WW, S, cnt - W, cnt - 2 * W + WW, B, l),
-                             3, stream)
-        extra['power_spectrum_fft'] = dict(ms=f_ms, nbins=nb, l=l)
+        Wb, WbWb = cnt - W, cnt - 2 * W + WW
+        ops.power_spectrum_fft(W, WW, S, Wb, WbWb, B, l)
+        f_ms = event_time_ms(lambda i: ops.power_spectrum_fft(W, WW, S, Wb, WbWb, B, l), 5)
+        extra['power_spectrum_fft'] = dict(ms=f_ms, nbins=nb, l=l,
+                                           algorithmic_GBps=5 * (8 * nb + 16 * (l // 4 + 1)) / (f_ms * 1e-3) / 1e9)
+        del cnt, W, WW, S, B, Wb, WbWb
         torch.cuda.empty_cache()
 
         # Bayesian Blocks at the C1 shape: ten years of daily cells from the same photons
-        bcells = data.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+        bcells = data0.get_cells(tcell=86400., use_barycenter=False, quiet=True)
         bcll = core.CellsLogLikelihood(bcells)
         bcll.do_bb(prior=8)
         torch.cuda.synchronize()
@@ -342,10 +510,12 @@ def main():
                                         interpolations_per_s=1000.0 * nb * (nb + 1) / 2 / tb[0])
         del bcll
         torch.cuda.empty_cache()
+    if cpu_other is not None:
+        extra['cpu_baselines'] = cpu_other
 
     line = {
         'metric': 'cells fit/s + photon×freq evals/s (1/2/4/8 GPU), % HBM/FP64 roofline',
-        'value': total_cells * args.steps / elapsed,
+        'value': cells_done / elapsed,
         'unit': 'cells/s',
         'n_gpus': world,
         'steps': args.steps,
@@ -356,10 +526,12 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': 'C2: %.0e photons, %g yr, %g-s cells (%d cells per GPU after '
-                               'trimming), batched alpha-hat + TS fit' % (
-                                   args.nph, args.years, args.tcell, ncell),
-                   'parallelism': 'one photon list per GPU, no collective in the timed steps; results all-gathered once afterwards'},
+        'config': {'workload': 'C2: %.0e photons, %g yr, %g-s cells (%d cells per list after trimming), batched '
+                               'alpha-hat + TS fit; %d lists per GPU fitted in rotation' % (
+                                   args.nph, args.years, args.tcell, ncells[0], NLIST),
+                   'parallelism': 'every GPU fits its own photon lists, no collective in the timed steps '
+                                  '(extra.strong_c2_fit and extra.strong_c4_z2m: one job split over the GPUs, '
+                                  'collectives timed)'},
         'roofline': roofline,
         'cpu_baseline': cpu,
         'extra': extra,
@@ -371,6 +543,13 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
+    run_rank(args)
 
 
 if __name__ == '__main__':

@@ -7,6 +7,12 @@ GodotError with the library's message.
 import ctypes
 import os
 
+# torch first: it brings its own copy of the HIP runtime (libamdhip64), and the library's
+# dependency on that name must resolve to the copy torch uses.  Loaded the other way round
+# the process holds two runtimes, and the library's launches see no device while torch's
+# tensors, whose pointers and streams it is handed, live in the other one.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GODOT_HIP_LIBRARY names another build of the same library (e.g. one under test)
 LIB_PATH = os.environ.get('GODOT_HIP_LIBRARY') or os.path.join(_HERE, 'libgodot_hip.so')
@@ -74,6 +80,7 @@ SIGNATURES = {
     'godot_power_spectrum_workspace_bytes': (c_size, [c_i64]),
     'godot_power_spectrum_fft': (c_int, [c_f64p] * 6 + [c_i64, c_i64] + [c_f64p] * 4
                                  + [c_ws, c_size, c_stream]),
+    'godot_power_spectrum_from_parts': (c_int, [c_f64p] * 5 + [c_i64] + [c_f64p] * 4 + [c_stream]),
     'godot_power_spectrum_simple': (c_int, [c_f64p] * 3 + [c_i64, c_f64p, c_f64p, c_ws, c_size,
                                                            c_stream]),
     'godot_trigsum_cells': (c_int, [c_f64p] * 4 + [c_i64, c_f64p, c_i64, c_f64, c_f64p, c_stream]),
@@ -101,6 +108,7 @@ SIGNATURES = {
     'godot_bb_workspace_bytes': (c_size, [c_i64, c_int]),
     'godot_bb_fitness': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_int, c_i64, c_i64, c_ws, c_f64p, c_f64p,
                                  c_stream]),
+    'godot_debug_spread_spin_limit': (c_int, [ctypes.c_long]),
     'godot_bb_partition': (c_int, [c_f64p, c_i64, c_f64, c_f64p, c_i64p, c_stream]),
 }
 

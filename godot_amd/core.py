@@ -604,6 +604,18 @@ def _raise_as_reference(flags, allow):
         raise RecursionError('the profile of a cell was re-centred 50 times without agreeing with its maximum')
 
 
+def _raise_unconverged_beta(flags, allow, alpha=None):
+    """get_beta_max raises a ValueError when its restarts run out (reference core.py:816-819);
+    the kernels mark such cells GODOT_F_FAILED and go on."""
+    if allow:
+        return
+    bad = (flags & 0x10) != 0
+    if bool(bad.any().cpu()):
+        i = int(torch.nonzero(bad)[0].cpu())
+        a = '' if alpha is None or not isinstance(alpha, torch.Tensor) else ' for alpha=%.5f' % float(alpha[i].cpu())
+        raise ValueError('Did not converge%s!' % a)
+
+
 class CellsLogLikelihood(object):
     """Batch driver: cached (ncell, 200) log-likelihood profiles, fluxes and
     the raw light curve (reference core.py:1070-1098, 1227-1336).
@@ -674,10 +686,12 @@ class CellsLogLikelihood(object):
         ag, xlo, xhi = ops.profile_quantiles(self._dom_d, self._cod_d, conf[0], conf[1])
         if self.profile_background:
             # core.py:1231-1245: beta guess from the profile, joint refit, profile TS
-            bg, _, _ = ops.cell_beta_max(self._cr, ag, swap=self._swap, want_logl=False)
+            bg, _, bf = ops.cell_beta_max(self._cr, ag, swap=self._swap, want_logl=False)
+            _raise_unconverged_beta(bf, self.allow_failed_cells, ag)
             aopt, _, _, _ = ops.cell_fit_joint(self._cr, guess_a=ag, guess_b=bg, swap=self._swap)
-            _, lp1, _ = ops.cell_beta_max(self._cr, aopt, swap=self._swap)
-            _, lp0, _ = ops.cell_beta_max(self._cr, 0.0, swap=self._swap)
+            _, lp1, bf1 = ops.cell_beta_max(self._cr, aopt, swap=self._swap)
+            _, lp0, bf0 = ops.cell_beta_max(self._cr, 0.0, swap=self._swap)
+            _raise_unconverged_beta(bf1 | bf0, self.allow_failed_cells, aopt)
             ts = 2 * (lp1 - lp0)
             s_eff = self._cr.B if self._swap else self._cr.S     # what get_ts tests: core.py:982-984, 343-345
             ts = torch.where((aopt == 0) | (s_eff == 0), torch.zeros_like(ts), ts)
@@ -769,8 +783,9 @@ class CellsLogLikelihood(object):
         if self.profile_background:
             aopt, _, _, fl = ops.cell_fit_joint(cr, swap=self._swap)
             dom, cod, _ = ops.cell_logpdf_profile(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
-            _, lp1, _ = ops.cell_beta_max(cr, aopt, swap=self._swap)
-            _, lp0, _ = ops.cell_beta_max(cr, 0.0, swap=self._swap)
+            _, lp1, bf1 = ops.cell_beta_max(cr, aopt, swap=self._swap)
+            _, lp0, bf0 = ops.cell_beta_max(cr, 0.0, swap=self._swap)
+            _raise_unconverged_beta(bf1 | bf0, self.allow_failed_cells, aopt)
             ts = 2 * (lp1 - lp0)
             s_eff = cr.B if self._swap else cr.S                 # what get_ts tests: core.py:982-984, 343-345
             ts = torch.where((aopt == 0) | (s_eff == 0), torch.zeros_like(ts), ts)

@@ -921,6 +921,7 @@ extern "C" int godot_exposure_table(const double *tstart, const double *tstop, c
                                     double b_over_e, void *table, size_t table_bytes,
                                     godot_stream_t stream)
 {
+    GODOT_ENTRY();
     ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
     return exposure_table_impl(ld, n_ft2, table, table_bytes, stream, "godot_exposure_table");
 }
@@ -930,6 +931,7 @@ extern "C" int godot_exposure_table_rows(const double *tstart, const double *tst
                                          const double *livetime, int64_t n_ft2, void *table,
                                          size_t table_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(sexposure && bexposure, GODOT_E_INVALID, "godot_exposure_table_rows: null scaled exposure");
     ExposureLoad ld{tstart, tstop, exposure, livetime, 0.0, 0.0, sexposure, bexposure};
     return exposure_table_impl(ld, n_ft2, table, table_bytes, stream, "godot_exposure_table_rows");
@@ -946,6 +948,7 @@ extern "C" int godot_exposure_at(const double *tstart, const double *tstop, cons
                                  double *out_exp, double *out_sexp, double *out_bexp, double *out_dead,
                                  void *workspace, size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     ExposureLoad ld{tstart, tstop, exposure, livetime, s_over_e, b_over_e};
     return exposure_at_impl(ld, n_ft2, table, times, n_t, cumulative, out_exp, out_sexp, out_bexp, out_dead,
                             workspace, workspace_bytes, stream, "godot_exposure_at");
@@ -958,6 +961,7 @@ extern "C" int godot_exposure_at_rows(const double *tstart, const double *tstop,
                                       double *out_sexp, double *out_bexp, double *out_dead, void *workspace,
                                       size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(sexposure && bexposure, GODOT_E_INVALID, "godot_exposure_at_rows: null scaled exposure");
     ExposureLoad ld{tstart, tstop, exposure, livetime, 0.0, 0.0, sexposure, bexposure};
     return exposure_at_impl(ld, n_ft2, table, times, n_t, cumulative, out_exp, out_sexp, out_bexp, out_dead,
@@ -967,6 +971,7 @@ extern "C" int godot_exposure_at_rows(const double *tstart, const double *tstop,
 extern "C" int godot_search_sorted(const double *sorted, int64_t n, const double *values, int64_t nv,
                                    int right, int64_t *out, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0 && nv >= 0, GODOT_E_INVALID, "godot_search_sorted: negative size");
     if (nv == 0) return GODOT_OK;
     GODOT_REQUIRE((sorted || n == 0) && values && out, GODOT_E_INVALID, "godot_search_sorted: null argument");
@@ -980,6 +985,7 @@ extern "C" int godot_piecewise_average(const double *starts, const double *stops
                                        const double *prod, const double *cprod, int64_t nseg, const double *t0,
                                        const double *t1, int64_t n, double *out, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nseg > 0 && n >= 0, GODOT_E_INVALID, "godot_piecewise_average: bad sizes");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(starts && stops && scales && prod && cprod && t0 && t1 && out, GODOT_E_INVALID,
@@ -993,6 +999,7 @@ extern "C" int godot_piecewise_average(const double *starts, const double *stops
 extern "C" int godot_piecewise_lookup(const double *stops, const double *scales, int64_t nseg,
                                       const double *t, int64_t n, double *out, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nseg > 0 && n >= 0, GODOT_E_INVALID, "godot_piecewise_lookup: bad sizes");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(stops && scales && t && out, GODOT_E_INVALID, "godot_piecewise_lookup: null argument");
@@ -1005,6 +1012,7 @@ extern "C" int godot_piecewise_lookup(const double *stops, const double *scales,
 extern "C" int godot_rescale_weights(const double *w, const double *a, double a0, const double *b, double b0,
                                      int64_t n, double *out, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_rescale_weights: negative size");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(w && out, GODOT_E_INVALID, "godot_rescale_weights: null argument");
@@ -1018,6 +1026,7 @@ extern "C" int godot_bin_photons(const double *ti, int64_t nph, double start0, c
                                  int64_t ncell, int64_t *lo, int64_t *hi, int64_t *counts,
                                  godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nph >= 0 && ncell >= 0, GODOT_E_INVALID, "godot_bin_photons: negative size");
     if (ncell == 0) return GODOT_OK;
     GODOT_REQUIRE((ti || nph == 0) && stops && lo && hi, GODOT_E_INVALID,
@@ -1038,6 +1047,7 @@ extern "C" int godot_select_cells(const double *exp, int64_t ncell, double thres
                                   int64_t *n_keep, void *workspace, size_t workspace_bytes,
                                   godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_select_cells: negative ncell");
     GODOT_REQUIRE(n_keep, GODOT_E_INVALID, "godot_select_cells: null n_keep");
     hipStream_t st = (hipStream_t)stream;
@@ -1109,6 +1119,7 @@ extern "C" int64_t godot_select_cells_static_max(void) { return SELECT_STATIC_MA
 extern "C" int godot_select_cells_static(const double *exp, int64_t ncell, double threshold, int64_t *keep_idx,
                                          int64_t *n_keep, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_select_cells_static: negative ncell");
     GODOT_REQUIRE(ncell <= SELECT_STATIC_MAX_TILES * SCAN_TILE, GODOT_E_UNSUPPORTED,
                   "godot_select_cells_static: %lld cells, the built-in scratch holds the counts of at most %lld "
@@ -1142,6 +1153,7 @@ extern "C" int godot_select_cells_static(const double *exp, int64_t ncell, doubl
 extern "C" int godot_gather_f64(const double *src, const int64_t *idx, int64_t n, double *dst,
                                 godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_gather_f64: negative n");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(src && idx && dst, GODOT_E_INVALID, "godot_gather_f64: null argument");
@@ -1154,6 +1166,7 @@ extern "C" int godot_gather_f64(const double *src, const int64_t *idx, int64_t n
 extern "C" int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n, int64_t *dst,
                                 godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_gather_i64: negative n");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(src && idx && dst, GODOT_E_INVALID, "godot_gather_i64: null argument");

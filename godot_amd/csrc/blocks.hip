@@ -371,6 +371,7 @@ extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t nc
                                 int64_t row_begin, int64_t row_end, void *workspace, double *fit_val,
                                 double *fit_arg, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_bb_fitness: negative ncell");
     GODOT_REQUIRE(npt >= 2, GODOT_E_INVALID, "godot_bb_fitness: npt must be at least 2");
     GODOT_REQUIRE(ngrid >= 2 && ngrid <= BB_MAX_GRID, GODOT_E_UNSUPPORTED,
@@ -401,6 +402,7 @@ extern "C" int godot_bb_fitness(const double *dom, const double *cod, int64_t nc
 extern "C" int godot_bb_partition(const double *fit_val, int64_t ncell, double prior, double *best,
                                   int64_t *last, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_bb_partition: negative ncell");
     GODOT_REQUIRE(ncell < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_bb_partition: too many cells");
     if (ncell == 0) return GODOT_OK;

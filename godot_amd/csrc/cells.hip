@@ -779,6 +779,7 @@ __global__ void met2mjd_kernel(const double *met, int64_t n, double per_day, dou
 
 extern "C" int godot_met2mjd(const double *met, int64_t n, double mjdref, double *mjd, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_met2mjd: negative n");
     if (n == 0) return GODOT_OK;
     GODOT_REQUIRE(met && mjd, GODOT_E_INVALID, "godot_met2mjd: null pointer");
@@ -793,6 +794,7 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
                               double guess0, const double *beta, double beta0, int swap,
                               double *alpha, double *ts, int32_t *flags, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_fit");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -821,6 +823,7 @@ extern "C" int godot_cell_loglike(const double *we, int64_t nph, const int64_t *
                                   const double *S, const double *B, int64_t ncell,
                                   const double *alpha, int swap, double *logl, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_loglike");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -837,6 +840,7 @@ extern "C" int godot_cell_sums(const double *we, int64_t nph, const int64_t *lo,
                                const double *alpha, double alpha0, const double *beta, double beta0, int swap,
                                double *sums, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_sums");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -851,6 +855,7 @@ extern "C" int godot_cell_sums(const double *we, int64_t nph, const int64_t *lo,
 extern "C" int godot_cell_moments(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                                   int64_t ncell, double *wsum, double *w2sum, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_moments");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -868,6 +873,7 @@ extern "C" int godot_cell_beta_max(const double *we, int64_t nph, const int64_t 
                                    double guess0, int swap, double *beta, double *logl_profile,
                                    int32_t *flags, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_beta_max");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -885,6 +891,7 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
                                  double dlogl, int npt, int include_zero, int swap, double *dom,
                                  double *cod, int32_t *flags, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_logpdf");
     if (rc) return rc;
     GODOT_REQUIRE(npt >= 2 && npt <= PQ_MAX_NPT, GODOT_E_UNSUPPORTED,
@@ -916,6 +923,7 @@ extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int
                                        double conf_lo, double conf_hi, double *aguess, double *xlo,
                                        double *xhi, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_profile_quantiles: negative ncell");
     GODOT_REQUIRE(npt >= 2 && npt <= PQ_MAX_NPT, GODOT_E_UNSUPPORTED,
                   "godot_profile_quantiles: npt must be in [2, %d]", PQ_MAX_NPT);
@@ -940,6 +948,7 @@ extern "C" int godot_lightcurve_rows(const double *tstart, const double *tstop, 
                                      const double *S, int64_t ncell, double tsmin, double *rows,
                                      godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_lightcurve_rows: negative ncell");
     if (ncell == 0) return GODOT_OK;
     GODOT_REQUIRE(tstart && tstop && alpha && ts && xlo && xhi && rows, GODOT_E_INVALID,

@@ -31,7 +31,7 @@ constexpr int SP_MAX_G = 64;          // workgroups per cell
 constexpr int SP_MAX_WG = 512;        // workgroups per launch
 constexpr int SP_SLOT = 4;            // doubles a workgroup publishes per exchange
 constexpr int64_t SP_MIN_SHARE = 8192;   // photons per workgroup below which spreading does not pay
-constexpr long SP_SPIN_LIMIT = 1L << 22;
+constexpr long SP_SPIN_LIMIT = 1L << 22;   // polls of a waiting workgroup before it gives the cell up (seconds)
 
 // Partial results of the workgroups (two generations, so that a workgroup may
 // publish exchange k + 1 while another still reads exchange k) and one arrival
@@ -39,16 +39,25 @@ constexpr long SP_SPIN_LIMIT = 1L << 22;
 // the host (spread_order below).
 __device__ double g_sp_slots[2 * SP_MAX_WG * SP_SLOT];
 __device__ unsigned g_sp_count[SP_MAX_WG];
+// Set for a cell by any of its workgroups that gave up waiting: the results of that launch
+// are not to be trusted for the cell, whichever workgroup wrote them, and the cell is fitted
+// again by one workgroup (the retry kernels below look at this word).
+__device__ unsigned g_sp_gave_up[SP_MAX_WG];
+__device__ long g_sp_spin_limit = SP_SPIN_LIMIT;
 
 __global__ void spread_reset_kernel()
 {
-    for (int i = threadIdx.x; i < SP_MAX_WG; i += blockDim.x) g_sp_count[i] = 0u;
+    for (int i = threadIdx.x; i < SP_MAX_WG; i += blockDim.x) {
+        g_sp_count[i] = 0u;
+        g_sp_gave_up[i] = 0u;
+    }
 }
 
 // What a workgroup of a spread cell needs to talk to the others.
 struct Spread {
     double *slots;     // this launch's slots: [2][ncell * G][SP_SLOT]
     unsigned *count;   // this cell's arrival counter
+    unsigned *gave_up; // this cell's word in g_sp_gave_up
     int64_t first;     // index of the cell's first workgroup among the launch's
     int g, G;
     double *xs;        // LDS: SP_SLOT * SP_MAX_G doubles
@@ -85,11 +94,16 @@ struct BlockCellT {
             __hip_atomic_fetch_add(sp.count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (gen + 1u) * (unsigned)G;
             if (!*sp.broken) {
+                const long limit = g_sp_spin_limit;
                 long spins = 0;
                 while (__hip_atomic_load(sp.count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > SP_SPIN_LIMIT) {   // seconds: the others never came; fail the cell, do not hang
+                    if (++spins > limit) {
+                        // The others never came (not all workgroups resident: the GPU is shared, or
+                        // busy with another launch).  Do not hang: tell the whole cell, whose other
+                        // workgroups may still finish and write results that lack this one's part.
                         *sp.broken = 1;
+                        __hip_atomic_store(sp.gave_up, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -368,13 +382,16 @@ __device__ __forceinline__ BlockSetup block_setup(const CellArgs &p, int64_t cel
 }
 
 // get_max + get_ts (core.py:632-739, 982-994), one workgroup per cell
+// retry: fit only the cells whose spread launch gave up (g_sp_gave_up) and mark them
 __global__ __launch_bounds__(BK_THREADS) void cell_fit_block_kernel(CellArgs p, const double *guess, double guess0,
                                                                     const double *beta, double beta0,
-                                                                    double *alpha, double *ts, int32_t *flags)
+                                                                    double *alpha, double *ts, int32_t *flags,
+                                                                    int retry)
 {
     __shared__ double s_red[3 * BK_WAVES];
     __shared__ int s_redi[BK_WAVES];
     const int64_t cell = blockIdx.x;
+    if (retry && g_sp_gave_up[cell] == 0u) return;
     const BlockSetup b = block_setup(p, cell);
     BlockCell cd{p.we + b.lo, b.n, (int)threadIdx.x, p.swap != 0, s_red, s_redi, {}};
     int fl = 0;
@@ -385,6 +402,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_block_kernel(CellArgs p, 
         a = fit_alpha(cd, b.S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
         if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, b.S, a);
     }
+    if (retry) fl |= GODOT_F_RETRIED;
     if (threadIdx.x == 0) {
         alpha[cell] = a;
         if (ts) ts[cell] = t;
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
                                                                        double dlogl, int npt, int include_zero,
                                                                        double *__restrict__ dom,
                                                                        double *__restrict__ cod,
-                                                                       int32_t *__restrict__ flags)
+                                                                       int32_t *__restrict__ flags, int retry)
 {
     __shared__ double s_red[3 * BK_WAVES];
     __shared__ int s_redi[BK_WAVES];
@@ -415,10 +433,11 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t cell = blockIdx.x;
+    if (retry && g_sp_gave_up[cell] == 0u) return;
     const bool swap = p.swap != 0;
     const BlockSetup b = block_setup(p, cell);
     BlockCell cd{p.we + b.lo, b.n, tid, swap, s_red, s_redi, {}};
-    int fl = 0;
+    int fl = retry ? GODOT_F_RETRIED : 0;
     bool ok = !b.bad;
     double aopt = qnan();
     if (b.bad) {
@@ -602,6 +621,7 @@ __device__ __forceinline__ SpreadSetup spread_setup(const CellArgs &p, int G, do
     s.nshare = s.j0 + share < s.b.n ? share : s.b.n - s.j0;
     s.sp.slots = g_sp_slots;
     s.sp.count = g_sp_count + cell;
+    s.sp.gave_up = g_sp_gave_up + cell;
     s.sp.first = cell * G;
     s.sp.g = g;
     s.sp.G = G;
@@ -635,6 +655,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_spread_kernel(CellArgs p,
     }
     __syncthreads();
     if (s_broken) {
+        // this cell is fitted again by cell_fit_block_kernel, launched right behind
         fl |= GODOT_F_FAILED;
         a = t = qnan();
     }
@@ -809,10 +830,21 @@ int spread_width(int dev, int64_t nph, int64_t ncell)
     if (g_order.cus[dev] == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1;
+        // every compute unit must be able to hold a workgroup of each spread kernel (the waiting
+        // workgroups have to be resident together): ask the runtime rather than assume it
+        int fit_per_cu = 0, grid_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_per_cu, (const void *)cell_fit_spread_kernel,
+                                                         BK_THREADS, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&grid_per_cu, (const void *)cell_logpdf_spread_kernel,
+                                                         BK_THREADS, 0) != hipSuccess ||
+            fit_per_cu < 1 || grid_per_cu < 1) {
+            (void)hipGetLastError();
+            cus = -1;
+        }
         g_order.cus[dev] = cus > 0 ? cus : -1;
     }
     if (g_order.cus[dev] <= 0) return 0;
-    int64_t width = g_order.cus[dev] / ncell;
+    int64_t width = g_order.cus[dev] / ncell;     // one workgroup per compute unit at most
     const int64_t by_size = nph / ncell / SP_MIN_SHARE;
     if (width > by_size) width = by_size;
     if (width > SP_MAX_G) width = SP_MAX_G;
@@ -821,7 +853,9 @@ int spread_width(int dev, int64_t nph, int64_t ncell)
 }
 
 // false: nothing was launched (the caller falls back to one workgroup per cell)
-bool spread_launch(const void *kernel, int64_t nph, int64_t ncell, void **args, int *width_arg, hipStream_t st)
+template <class Retry>
+bool spread_launch(const void *kernel, int64_t nph, int64_t ncell, void **args, int *width_arg, hipStream_t st,
+                   Retry retry)
 {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return false;
@@ -843,18 +877,38 @@ bool spread_launch(const void *kernel, int64_t nph, int64_t ncell, void **args, 
     // An ordinary launch: ncell * G is at most the number of compute units, each of which holds
     // such a workgroup, and no other launch that waits inside a kernel runs beside this one, so
     // every workgroup becomes resident without any of those already waiting having to leave.
-    // (hipLaunchCooperativeKernel would state that to the runtime, but a process that has used it
-    // ends in a segmentation fault at exit under rocprofv3's kernel trace.)
+    // hipLaunchCooperativeKernel gives the same residency (it only checks the grid against the
+    // occupancy query, which spread_width has asked already) and a process that has used it dies
+    // in an exit handler after rocprofv3 has finalised its tool.  Should the workgroups not become
+    // resident together all the same (a GPU shared with another process), the waits run out, the
+    // cell is marked and the retry launch below fits it.
     const hipError_t e = hipLaunchKernel(kernel, dim3((unsigned)(ncell * G)), dim3(BK_THREADS), args, 0, st);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
+    // cells whose workgroups gave up waiting for each other (a shared or busy GPU) are fitted
+    // again, one workgroup each: a launch whose workgroups leave at once when no cell did
+    retry();
     (void)hipEventRecord(g_order.last[dev], st);
     return true;
 }
 
 }   // namespace
+
+// Test hook: how many polls a workgroup of a spread cell waits for the others before it
+// gives the cell up to the retry launch (default 2^22: seconds).  0 restores the default.
+extern "C" int godot_debug_spread_spin_limit(long polls)
+{
+    GODOT_ENTRY();
+    const long v = polls > 0 ? polls : SP_SPIN_LIMIT;
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_sp_spin_limit), &v, sizeof(v));
+    if (e != hipSuccess) {
+        godot_set_error("godot_debug_spread_spin_limit: %s", hipGetErrorString(e));
+        return GODOT_E_LAUNCH;
+    }
+    return GODOT_OK;
+}
 
 namespace godot_detail {
 
@@ -880,10 +934,14 @@ void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const in
     {
         int G = 0;
         void *args[] = {&p, &G, &guess, &guess0, &beta, &beta0, &alpha, &ts, &flags};
-        if (spread_launch((const void *)cell_fit_spread_kernel, nph, ncell, args, &G, st)) return;
+        auto retry = [&]() {
+            hipLaunchKernelGGL(cell_fit_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, guess,
+                               guess0, beta, beta0, alpha, ts, flags, 1);
+        };
+        if (spread_launch((const void *)cell_fit_spread_kernel, nph, ncell, args, &G, st, retry)) return;
     }
     hipLaunchKernelGGL(cell_fit_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, guess, guess0,
-                       beta, beta0, alpha, ts, flags);
+                       beta, beta0, alpha, ts, flags, 0);
 }
 
 void logpdf_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
@@ -894,10 +952,14 @@ void logpdf_block_launch(const double *we, int64_t nph, const int64_t *lo, const
     {
         int G = 0;
         void *args[] = {&p, &G, &aopt, &dlogl, &npt, &include_zero, &dom, &cod, &flags};
-        if (spread_launch((const void *)cell_logpdf_spread_kernel, nph, ncell, args, &G, st)) return;
+        auto retry = [&]() {
+            hipLaunchKernelGGL(cell_logpdf_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, we,
+                               aopt, dlogl, npt, include_zero, dom, cod, flags, 1);
+        };
+        if (spread_launch((const void *)cell_logpdf_spread_kernel, nph, ncell, args, &G, st, retry)) return;
     }
     hipLaunchKernelGGL(cell_logpdf_block_kernel, dim3((unsigned)ncell), dim3(BK_THREADS), 0, st, p, we, aopt,
-                       dlogl, npt, include_zero, dom, cod, flags);
+                       dlogl, npt, include_zero, dom, cod, flags, 0);
 }
 
 }   // namespace godot_detail

@@ -355,6 +355,7 @@ extern "C" int godot_cell_fit_joint(const double *we, int64_t nph, const int64_t
                                     double *alpha, double *beta, double *logl, int32_t *flags,
                                     godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_fit_joint");
     if (rc) return rc;
     if (ncell == 0) return GODOT_OK;
@@ -371,6 +372,7 @@ extern "C" int godot_cell_logpdf_profile(const double *we, int64_t nph, const in
                                          const double *aopt, double dlogl, int npt, int swap, double *dom,
                                          double *cod, int32_t *flags, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_logpdf_profile");
     if (rc) return rc;
     GODOT_REQUIRE(npt >= 2 && npt <= 1024, GODOT_E_UNSUPPORTED,

@@ -18,6 +18,12 @@ void godot_set_error(const char *fmt, ...);
         }                                         \
     } while (0)
 
+// First statement of every entry point that launches kernels: hipGetLastError keeps the
+// error of whatever HIP call failed last in this host thread, the caller's own included
+// (a device query before the runtime was up, say), and GODOT_LAUNCH_CHECK would report
+// that stale error as this call's.
+#define GODOT_ENTRY() (void)hipGetLastError()
+
 #define GODOT_LAUNCH_CHECK(what)                                              \
     do {                                                                      \
         hipError_t e_ = hipGetLastError();                                    \

@@ -418,6 +418,57 @@ __global__ void ps_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx *Z2, i
     if (pb) pb[k] = dl_null;
 }
 
+// The same estimators from the five transforms handed over one by one, each cut to
+// what the estimators read: F1 = rfft(W - S)[:nk], F2 = rfft(Wb - B)[:nk] and the even
+// bins G3 = rfft(WW)[0 : 2 nk : 2], G4 = rfft(WbWb)[...], G5 = rfft(W - WW)[...]
+// (core.py:2683-2741) -- the form in which transforms computed on different GPUs arrive.
+__global__ void ps_epilogue_parts_kernel(const cplx *F1, const cplx *F2, const cplx *G3, const cplx *G4,
+                                         const cplx *G5, int64_t nk, double *p0, double *p1, double *pb,
+                                         double *amps)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    const cplx f1 = F1[k], f2 = F2[k];
+    double WmS_cos = f1.x, WmS_sin = -f1.y;
+    double WbmB_cos = f2.x, WbmB_sin = -f2.y;
+    const double S2 = G3[0].x, B2 = G4[0].x, SB = G5[0].x;
+    const double g3 = G3[k].x, g4 = G4[k].x, g5 = G5[k].x;
+    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
+    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
+    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
+    if (k == 0) {
+        WW_sin = 1.;
+        WbWb_sin = 1.;
+    }
+    double a_cos0 = WmS_cos / WW_cos;
+    double a_sin0 = WmS_sin / WW_sin;
+    double b_cos0 = WbmB_cos / WbWb_cos;
+    double b_sin0 = WbmB_sin / WbWb_sin;
+    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
+    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
+    if (k == 0) den_sin = 0.;
+    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
+    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
+    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
+    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
+    if (amps) {
+        amps[0 * nk + k] = a_cos;
+        amps[1 * nk + k] = a_sin;
+        amps[2 * nk + k] = b_cos;
+        amps[3 * nk + k] = b_sin;
+        amps[4 * nk + k] = a_cos0;
+        amps[5 * nk + k] = a_sin0;
+        amps[6 * nk + k] = b_cos0;
+        amps[7 * nk + k] = b_sin0;
+    }
+    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
+    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
+    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
+    if (p0) p0[k] = dl_nobg;
+    if (p1) p1[k] = dl - dl_null;
+    if (pb) pb[k] = dl_null;
+}
+
 // power_spectrum_simple epilogue (core.py:2766-2782)
 __global__ void ps_simple_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx *Z2, int64_t N2, int64_t nk,
                                           double *dlogl, double *moments)
@@ -613,6 +664,7 @@ extern "C" size_t godot_rfft_workspace_bytes(int64_t l)
 extern "C" int godot_rfft_f64(const double *x, int64_t n, int64_t l, double *out, void *workspace,
                               size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 0 && l >= 2, GODOT_E_INVALID, "godot_rfft_f64: need n >= 0 and l >= 2");
     GODOT_REQUIRE(l < ((int64_t)1 << 40), GODOT_E_UNSUPPORTED, "godot_rfft_f64: l too large");
     GODOT_REQUIRE((x || n == 0) && out, GODOT_E_INVALID, "godot_rfft_f64: null argument");
@@ -651,6 +703,7 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
                                         double *p1, double *pb, double *amps, void *workspace,
                                         size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 1 && l >= 8, GODOT_E_INVALID, "godot_power_spectrum_fft: need n >= 1 and l >= 8");
     GODOT_REQUIRE(l < ((int64_t)1 << 40), GODOT_E_UNSUPPORTED, "godot_power_spectrum_fft: l too large");
     GODOT_REQUIRE(n <= l, GODOT_E_INVALID, "godot_power_spectrum_fft: n exceeds the padded length");
@@ -695,10 +748,25 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
     return GODOT_OK;
 }
 
+extern "C" int godot_power_spectrum_from_parts(const double *f1, const double *f2, const double *g3,
+                                               const double *g4, const double *g5, int64_t nk, double *p0,
+                                               double *p1, double *pb, double *amps, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(nk >= 1, GODOT_E_INVALID, "godot_power_spectrum_from_parts: need nk >= 1");
+    GODOT_REQUIRE(f1 && f2 && g3 && g4 && g5, GODOT_E_INVALID, "godot_power_spectrum_from_parts: null transform");
+    hipLaunchKernelGGL(ps_epilogue_parts_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const cplx *)f1, (const cplx *)f2, (const cplx *)g3,
+                       (const cplx *)g4, (const cplx *)g5, nk, p0, p1, pb, amps);
+    GODOT_LAUNCH_CHECK("godot_power_spectrum_from_parts");
+    return GODOT_OK;
+}
+
 extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, const double *S, int64_t n,
                                            double *dlogl, double *moments, void *workspace,
                                            size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 8, GODOT_E_INVALID, "godot_power_spectrum_simple: need n >= 8");
     GODOT_REQUIRE(W && WW && S, GODOT_E_INVALID, "godot_power_spectrum_simple: null series");
     GODOT_REQUIRE(workspace && workspace_bytes >= godot_power_spectrum_workspace_bytes(n), GODOT_E_WORKSPACE,

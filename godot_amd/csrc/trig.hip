@@ -568,6 +568,7 @@ __global__ void orbital_update_kernel(const double *starts, const double *stops,
 extern "C" int godot_ls_cells(const double *flux, const double *tmid, int64_t ncell, const double *freqs,
                               int64_t nfreq, double *power, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 1 && nfreq >= 0, GODOT_E_INVALID, "godot_ls_cells: bad sizes");
     GODOT_REQUIRE(nfreq < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_ls_cells: too many frequencies");
     if (nfreq == 0) return GODOT_OK;
@@ -585,6 +586,7 @@ extern "C" int godot_orbital_modulation_step(const double *starts, const double 
                                              double *rvals, void *workspace, size_t workspace_bytes,
                                              godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(n >= 1, GODOT_E_INVALID, "godot_orbital_modulation_step: n must be positive");
     GODOT_REQUIRE(starts && stops && y && z && means && rvals, GODOT_E_INVALID,
                   "godot_orbital_modulation_step: null argument");
@@ -615,6 +617,7 @@ extern "C" int godot_z2m(const double *t, const double *w, int64_t nph, double f
                          int64_t nf, int m, double *z2, double *h, void *workspace, size_t workspace_bytes,
                          godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nph >= 0 && nf >= 0 && j0 >= 0, GODOT_E_INVALID, "godot_z2m: negative size");
     GODOT_REQUIRE(m >= 1 && m <= 20, GODOT_E_UNSUPPORTED, "godot_z2m: m must be in [1, 20]");
     GODOT_REQUIRE(j0 + nf < ((int64_t)1 << 52), GODOT_E_UNSUPPORTED, "godot_z2m: frequency index too large");
@@ -649,6 +652,7 @@ extern "C" int godot_z2m_sums(const double *t, const double *w, int64_t nph, dou
                               int64_t nf, int m, double *sums, double *sumw2_out, void *workspace,
                               size_t workspace_bytes, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nph >= 0 && nf >= 0 && j0 >= 0, GODOT_E_INVALID, "godot_z2m_sums: negative size");
     GODOT_REQUIRE(m >= 1 && m <= 20, GODOT_E_UNSUPPORTED, "godot_z2m_sums: m must be in [1, 20]");
     GODOT_REQUIRE(j0 + nf < ((int64_t)1 << 52), GODOT_E_UNSUPPORTED,
@@ -689,6 +693,7 @@ extern "C" int godot_z2m_sums(const double *t, const double *w, int64_t nph, dou
 extern "C" int godot_z2m_finish(const double *sums, const double *sumw2, int64_t nf, int m, double *z2,
                                 double *h, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(nf >= 0, GODOT_E_INVALID, "godot_z2m_finish: negative size");
     GODOT_REQUIRE(m >= 1 && m <= 20, GODOT_E_UNSUPPORTED, "godot_z2m_finish: m must be in [1, 20]");
     if (nf == 0) return GODOT_OK;
@@ -704,6 +709,7 @@ extern "C" int godot_trigsum_cells(const double *w1, const double *w2, const dou
                                    int64_t ncell, const double *freqs, int64_t nfreq, double exp_scale,
                                    double *power, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 2 && nfreq >= 0, GODOT_E_INVALID,
                   "godot_trigsum_cells: needs at least two cells (the cell spacing enters the statistic)");
     GODOT_REQUIRE(nfreq < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_trigsum_cells: too many frequencies");
@@ -720,6 +726,7 @@ extern "C" int godot_fit_harmonics(const double *w1, const double *w2, const dou
                                    int64_t ncell, double tmean, const double *freqs, int64_t nfreq,
                                    double *out, godot_stream_t stream)
 {
+    GODOT_ENTRY();
     GODOT_REQUIRE(ncell >= 1 && nfreq >= 0, GODOT_E_INVALID, "godot_fit_harmonics: bad sizes");
     GODOT_REQUIRE(nfreq < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED, "godot_fit_harmonics: too many frequencies");
     if (nfreq == 0) return GODOT_OK;

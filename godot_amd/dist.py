@@ -8,7 +8,9 @@ The path shards without any data-path exchange:
     list is replicated (16 MB for 1e6 photons);
   * multi-source batches: sources dealt round-robin;
   * Bayesian-Blocks fitness rows: contiguous row ranges balanced by row length
-    (row i costs i + 1 cell profiles); the profiles are replicated.
+    (row i costs i + 1 cell profiles); the profiles are replicated;
+  * the FFT power spectrum: its five real transforms dealt over up to five
+    ranks, the parts of the spectra that the estimators read all-gathered.
 The only collectives there are result collection: an all-gather of
 fixed-width per-cell records (padded to the largest shard) and, for searches,
 an all-reduce(max) / all-gather of per-rank maxima.  Both are latency-bound
@@ -75,10 +77,11 @@ def source_shard(nsource, rank=None, world=None, group=None):
 def all_gather_ragged(local, sizes=None, group=None):
     """Concatenate per-rank tensors with different first dimensions, in rank
     order, on every rank.  One all-gather of the sizes, one of the padded
-    records."""
+    records.  (Under the gloo backend the records are gathered on the host.)"""
     rank, world = _world(group)
     if world == 1:
         return local
+    local = local.to(_device_of(group))
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     if sizes is None:
         allsz = torch.empty(world, dtype=torch.int64, device=local.device)
@@ -130,6 +133,7 @@ def search_topk_sharded(nf, search_fn, k=10, group=None):
         rec[:kk, 0] = v.to(torch.float64)
         rec[:kk, 1] = (i + j0).to(torch.float64)
     if world > 1:
+        rec = rec.to(_device_of(group))
         allrec = torch.empty((world * k, 2), dtype=torch.float64, device=rec.device)
         dist.all_gather_into_tensor(allrec, rec.contiguous(), group=group)
         rec = allrec
@@ -152,6 +156,7 @@ def search_sharded(nf, search_fn, gather_spectrum=False, group=None):
     else:
         best = torch.tensor([-np.inf, -1.0], dtype=torch.float64, device=z.device)
     if world > 1:
+        best = best.to(_device_of(group))
         allbest = torch.empty((world, 2), dtype=torch.float64, device=best.device)
         dist.all_gather_into_tensor(allbest, best.unsqueeze(0).contiguous(), group=group)
         k = int(torch.argmax(allbest[:, 0]).cpu())
@@ -231,3 +236,59 @@ def bb_fitness_sharded(ncell, rows_fn, group=None):
     rec = all_gather_ragged(torch.stack([fv, fa], dim=1), sizes=sizes, group=group)
     return rec[:, 0].contiguous(), rec[:, 1].contiguous()
 
+
+
+def transform_shard(ntransform=5, rank=None, world=None, group=None):
+    """Indices of the transforms (of ntransform) that this rank computes: dealt round-robin
+    over the first min(world, ntransform) ranks, the others get none."""
+    r, w = _world(group)
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return list(range(rank, ntransform, min(world, ntransform))) if rank < ntransform else []
+
+
+def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None):
+    """power_spectrum_fft (reference core.py:2683-2741) with its five real transforms of
+    length l dealt over the ranks (one whole transform per rank and turn: the spectrum of a
+    twelve-year light curve in 100-s bins, l = 2**25, is 268 MB, a single GPU transforms it
+    in a fraction of a millisecond, so a transform is not split further).
+
+    series_fn   : callable(i) -> the i-th series on this rank's device, i = 0 .. 4 for
+                  W - S, Wb - B, WW, WbWb, W - WW (unpadded; formed only for the
+                  transforms this rank owns)
+    rfft_fn     : callable(series, l) -> (l/2 + 1, 2) tensor of (re, im), numpy.fft.rfft(x, n=l)
+    estimate_fn : callable(f1, f2, g3, g4, g5) -> the estimators from the five parts,
+                  each (nk, 2) with nk = l/4 + 1 (ops.power_spectrum_from_parts)
+    Every rank cuts its transforms to the nk entries the estimators read (the first nk bins
+    of the first two, the even bins of the other three: half of each spectrum), one
+    all-gather collects them (5 * 16 * nk bytes in all; 671 MB at l = 2**25), and every rank
+    forms the estimators.  Returns what estimate_fn returns."""
+    rank, world = _world(group)
+    nk = l // 4 + 1
+    mine = transform_shard(5, rank, world)
+    parts = {}
+    for i in mine:
+        f = rfft_fn(series_fn(i), l)
+        parts[i] = (f[:nk] if i < 2 else f[0:2 * nk:2][:nk]).contiguous()
+    if world > 1:
+        slots = -(-5 // min(world, 5))
+        ref = next(iter(parts.values())) if parts else None
+        dev = ref.device if ref is not None else _device_of(group)
+        dtype = ref.dtype if ref is not None else torch.float64
+        buf = torch.zeros((slots, nk, 2), dtype=dtype, device=dev)
+        for s_, i in enumerate(mine):
+            buf[s_] = parts[i]
+        allbuf = torch.empty((world * slots, nk, 2), dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(allbuf, buf, group=group)
+        allbuf = allbuf.view(world, slots, nk, 2)
+        for r in range(min(world, 5)):
+            for s_, i in enumerate(transform_shard(5, r, world)):
+                parts[i] = allbuf[r, s_]
+    return estimate_fn(parts[0], parts[1], parts[2], parts[3], parts[4])
+
+
+def _device_of(group=None):
+    """Device of the collectives of this process: the current GPU under nccl, the host under gloo."""
+    if dist.is_initialized() and dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')

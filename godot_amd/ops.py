@@ -444,6 +444,26 @@ def power_spectrum_fft(W, WW, S, Wb, WbWb, B, l, want_amps=False):
     return p0, p1, pb, amps
 
 
+def power_spectrum_from_parts(f1, f2, g3, g4, g5, want_amps=False):
+    """(p0, p1, pb, amps) of power_spectrum_fft from its five transforms, each an (nk, 2)
+    tensor of (re, im): rfft(W - S)[:nk], rfft(Wb - B)[:nk] and the even bins
+    rfft(.)[0 : 2 nk : 2] of WW, WbWb and W - WW."""
+    nk = f1.shape[0]
+    for t, nm in ((f1, 'f1'), (f2, 'f2'), (g3, 'g3'), (g4, 'g4'), (g5, 'g5')):
+        _dev_check(t, F64, nm)
+        if tuple(t.shape) != (nk, 2):
+            raise ValueError('%s must have shape (nk, 2)' % nm)
+    dev = f1.device
+    p0 = torch.empty(nk, dtype=F64, device=dev)
+    p1 = torch.empty(nk, dtype=F64, device=dev)
+    pb = torch.empty(nk, dtype=F64, device=dev)
+    amps = torch.empty((8, nk), dtype=F64, device=dev) if want_amps else None
+    with torch.cuda.device(dev):
+        _lib.call('godot_power_spectrum_from_parts', _p(f1), _p(f2), _p(g3), _p(g4), _p(g5), nk, _p(p0), _p(p1),
+                  _p(pb), _p(amps), _stream(dev))
+    return p0, p1, pb, amps
+
+
 def power_spectrum_simple(W, WW, S, want_moments=False):
     for t, nm in ((W, 'W'), (WW, 'WW'), (S, 'S')):
         _dev_check(t, F64, nm)

@@ -48,6 +48,9 @@ extern "C" {
 #define GODOT_F_BRENT       0x08  /* bracketing root finder was used           */
 #define GODOT_F_FAILED      0x10  /* no bracket / no convergence: output NaN   */
 #define GODOT_F_RECENTRED   0x20  /* profile grid was re-centred at least once */
+#define GODOT_F_RETRIED     0x40  /* a very large cell spread over several workgroups was fitted
+                                     again by one: the workgroups did not all become resident
+                                     together (shared or busy GPU); the result is as good */
 
 typedef void *godot_stream_t;
 
@@ -334,6 +337,18 @@ int godot_power_spectrum_fft(const double *W, const double *WW, const double *S,
                              void *workspace, size_t workspace_bytes,
                              godot_stream_t stream);
 
+/* The estimators of power_spectrum_fft (core.py:2707-2741) from the five
+ * transforms handed over one by one, each an array of nk (re, im) pairs cut to
+ * what the estimators read: f1 = rfft(W - S)[:nk], f2 = rfft(Wb - B)[:nk],
+ * g3 = rfft(WW)[0 : 2 nk : 2], g4 = rfft(WbWb)[0 : 2 nk : 2],
+ * g5 = rfft(W - WW)[0 : 2 nk : 2] (core.py:2683-2704), nk = l/4 + 1.  This is
+ * the form in which transforms computed on different GPUs arrive after their
+ * all-gather; outputs as godot_power_spectrum_fft.                            */
+int godot_power_spectrum_from_parts(const double *f1, const double *f2, const double *g3,
+                                    const double *g4, const double *g5, int64_t nk,
+                                    double *p0, double *p1, double *pb, double *amps,
+                                    godot_stream_t stream);
+
 /* power_spectrum_simple (core.py:2758-2782): l = n, any length >= 8.
  * moments (may be NULL) receives (cos, sin, cc, ss), [4][l/4+1].              */
 int godot_power_spectrum_simple(const double *W, const double *WW,
@@ -437,6 +452,11 @@ int godot_bb_fitness(const double *dom, const double *cod, int64_t ncell, int np
  * (core.py:1164-1169) is left to the host.                                    */
 int godot_bb_partition(const double *fit_val, int64_t ncell, double prior,
                        double *best, int64_t *last, godot_stream_t stream);
+
+/* Test hook (no counterpart in the reference): polls that a workgroup of a cell
+ * spread over several workgroups waits for the others before the cell goes to
+ * the one-workgroup retry; 0 restores the default (2^22, seconds).  Synchronous. */
+int godot_debug_spread_spin_limit(long polls);
 
 #ifdef __cplusplus
 }

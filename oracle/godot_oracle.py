@@ -617,19 +617,30 @@ def power_spectrum_fft(starts, stops, counts, W, WW, sexp, bexp, dfgoal=None,
     freqs = np.fft.rfftfreq(l) / tsamp
     nk = l // 4 + 1
 
-    f = np.fft.rfft(W - S)[:nk]
-    WmS_cos, WmS_sin = np.real(f), -np.imag(f)
-    f = np.fft.rfft(Wb - B)[:nk]
-    WbmB_cos, WbmB_sin = np.real(f), -np.imag(f)
+    out = power_spectrum_from_parts(np.fft.rfft(W - S)[:nk], np.fft.rfft(Wb - B)[:nk], np.fft.rfft(WW)[::2],
+                                    np.fft.rfft(WbWb)[::2], np.fft.rfft(W - WW)[::2], get_amps=get_amps)
+    if get_amps:
+        return (freqs[:nk],) + out
+    if exp_only:
+        return freqs[:nk], out[0]
+    return (freqs[:nk],) + out
 
-    def halves(x):
-        f = np.fft.rfft(x)
+
+def power_spectrum_from_parts(f1, f2, g3, g4, g5, get_amps=False):
+    """The estimators of power_spectrum_fft (core.py:2685-2741) from its five transforms:
+    f1 = rfft(W - S)[:nk], f2 = rfft(Wb - B)[:nk] and the even bins of rfft(WW), rfft(WbWb)
+    and rfft(W - WW) (complex arrays of nk entries).  Returns (P0, P1, Pb), or the eight
+    amplitude arrays with get_amps."""
+    WmS_cos, WmS_sin = np.real(f1), -np.imag(f1)
+    WbmB_cos, WbmB_sin = np.real(f2), -np.imag(f2)
+
+    def halves(f):
         s0 = f[0].real
-        return 0.5 * (s0 + np.real(f)[::2]), 0.5 * (s0 - np.real(f)[::2])
+        return 0.5 * (s0 + np.real(f)), 0.5 * (s0 - np.real(f))
 
-    WW_cos, WW_sin = halves(WW)
-    WbWb_cos, WbWb_sin = halves(WbWb)
-    WWb_cos, WWb_sin = halves(W - WW)
+    WW_cos, WW_sin = halves(g3)
+    WbWb_cos, WbWb_sin = halves(g4)
+    WWb_cos, WWb_sin = halves(g5)
     WW_sin[0] = 1.
     WbWb_sin[0] = 1.
 
@@ -646,15 +657,12 @@ def power_spectrum_fft(starts, stops, counts, W, WW, sexp, bexp, dfgoal=None,
         b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos
         b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin
         if get_amps:
-            return (freqs[:nk], a_cos, a_sin, b_cos, b_sin,
-                    a_cos0, a_sin0, b_cos0, b_sin0)
+            return (a_cos, a_sin, b_cos, b_sin, a_cos0, a_sin0, b_cos0, b_sin0)
         dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin
         dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin
         dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos \
             + b_sin * WbmB_sin
-    if exp_only:
-        return freqs[:nk], dl_nobg
-    return freqs[:nk], dl_nobg, dl - dl_null, dl_null
+    return dl_nobg, dl - dl_null, dl_null
 
 
 def power_spectrum_simple(starts, stops, W, WW, sexp, get_amps=False):

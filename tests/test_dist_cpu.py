@@ -94,7 +94,37 @@ def _worker(rank, world, port, q):
         fv, fa = gd.bb_fitness_sharded(nb, rows_fn)
         rv, ra = rows_fn(0, nb)
         ok3 = bool(torch.equal(fv, rv)) and bool(torch.equal(fa, ra))
-        q.put((rank, ok1, ok2 and ok3, (c0, c1), gd.source_shard(7)))
+        # FFT power spectrum with its five transforms dealt over the ranks (numpy's rfft as
+        # the per-rank transform): every rank ends with the oracle's spectra, to the bit
+        nbin = 300
+        cnt = rng.poisson(3.0, nbin).astype(float)
+        W = cnt * rng.uniform(0.1, 0.3, nbin)
+        WW = W * rng.uniform(0.2, 0.6, nbin)
+        Sx = np.full(nbin, W.mean() * 1.1)
+        Bx = np.full(nbin, (cnt - W).mean() * 0.9)
+        starts = 100. * np.arange(nbin)
+        ref_ps = orc.power_spectrum_fft(starts, starts + 100., cnt, W, WW, Sx, Bx)
+        l = 4 * (len(ref_ps[0]) - 1)
+        Wb, WbWb = cnt - W, cnt - 2 * W + WW
+        series = [W - Sx, Wb - Bx, WW, WbWb, W - WW]
+        made = []
+
+        def series_fn(i):
+            made.append(i)
+            return series[i]
+
+        def rfft_fn(x, n):
+            f = np.fft.rfft(x, n=n)
+            return torch.from_numpy(np.stack([f.real, f.imag], axis=1))
+
+        def estimate_fn(*parts):
+            c = [p_.numpy()[:, 0] + 1j * p_.numpy()[:, 1] for p_ in parts]
+            return orc.power_spectrum_from_parts(*c)
+
+        ps = gd.power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn)
+        ok4 = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ps, ref_ps[1:]))
+        ok4 = ok4 and made == gd.transform_shard(5) and made == list(range(rank, 5, world))
+        q.put((rank, ok1, ok2 and ok3 and ok4, (c0, c1), gd.source_shard(7)))
     finally:
         dist.destroy_process_group()
 
@@ -134,6 +164,10 @@ def test_shard_helpers_single_process():
         tot += n
     assert tot == 10
     assert gd.frequency_shard(2, 3, 4) == (2, 0)
+    # five transforms over up to five ranks; further ranks get none
+    assert [gd.transform_shard(5, r, 2) for r in range(2)] == [[0, 2, 4], [1, 3]]
+    assert [gd.transform_shard(5, r, 8) for r in range(8)] == [[0], [1], [2], [3], [4], [], [], []]
+    assert gd.transform_shard(5, 0, 1) == [0, 1, 2, 3, 4]
     b = gd.split_by_weight(np.array([0, 10, 20, 30, 40]), 2)
     assert list(b) == [0, 2, 4]
     # fitness rows: contiguous cover, work (sum of row lengths) within a row of equal

@@ -438,6 +438,42 @@ def test_very_large_cells_by_layout(shape):
             assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), c
 
 
+def test_spread_cells_whose_workgroups_give_up_waiting_are_fitted_again():
+    """The workgroups of a spread cell wait for each other a bounded time (they are resident
+    together unless the GPU is shared or busy).  With the wait cut to one poll nearly every
+    exchange runs out: the cells are marked, fitted again by one workgroup each, and come out
+    with the results of an undisturbed run and the GODOT_F_RETRIED bit, never failed."""
+    from godot_amd import ops, _lib
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    cnt = np.array([300001, 280000, 355003, 290000], dtype=np.int64)
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = cnt * 0.17 * np.array([0.4, 1.0, 2.5, 1.0])
+    cr = ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                     torch.from_numpy(S).to(dev), torch.from_numpy(S * 5).to(dev))
+    a0, t0, f0 = ops.cell_fit(cr)
+    d0, c0, g0 = ops.cell_logpdf(cr, dlogl=20, npt=100)
+    torch.cuda.synchronize()
+    assert not ((f0 | g0).cpu().numpy() & 0x50).any()          # neither failed nor retried
+    try:
+        _lib.call('godot_debug_spread_spin_limit', 1)
+        a1, t1, f1 = ops.cell_fit(cr)
+        d1, c1, g1 = ops.cell_logpdf(cr, dlogl=20, npt=100)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call('godot_debug_spread_spin_limit', 0)
+    f1, g1 = f1.cpu().numpy(), g1.cpu().numpy()
+    assert not ((f1 | g1) & 0x10).any()
+    assert (f1 & 0x40).any() and (g1 & 0x40).any()             # the retry path did run
+    rel = lambda x, y: float(((x - y).abs() / y.abs().clamp(min=1.0)).max())
+    assert rel(a1, a0) < 1e-12 and rel(t1, t0) < 1e-10
+    assert rel(d1, d0) < 1e-12 and rel(c1, c0) < 1e-10
+    # and the default wait is back: an undisturbed run again
+    a2, t2, f2 = ops.cell_fit(cr)
+    assert torch.equal(a2, a0) and torch.equal(t2, t0) and not (f2.cpu().numpy() & 0x40).any()
+
+
 @pytest.mark.parametrize('given', [False, True])
 def test_profiles_of_few_moderately_large_cells(given):
     """Up to 4096 cells of 1024 photons or more each (ten years of daily cells of a bright

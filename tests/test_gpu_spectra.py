@@ -230,3 +230,31 @@ def test_z2m_signal_and_exactness_at_large_phase():
     nf = 256 * 20 * 1024     # whole residency rounds: not split
     zbig, _ = ops.z2m(torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV), f0, df, nf, m=2)
     assert np.abs(_n(zbig[:101]) - z).max() <= 1e-9 * z.max()
+
+
+def test_spectrum_from_separately_transformed_series():
+    """power_spectrum_fft put together from five stand-alone transforms (what ranks that
+    each own some of the transforms exchange) equals the fused call and the oracle."""
+    from godot_amd import ops, dist as gd
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(31)
+    nbin, l = 5000, 1 << 15
+    cnt = rng.poisson(3.0, nbin).astype(float)
+    W = cnt * rng.uniform(0.1, 0.3, nbin)
+    WW = W * rng.uniform(0.2, 0.6, nbin)
+    S = np.full(nbin, W.mean() * 1.05)
+    B = np.full(nbin, (cnt - W).mean() * 0.95)
+    Wb, WbWb = cnt - W, cnt - 2 * W + WW
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    series = [d(W - S), d(Wb - B), d(WW), d(WbWb), d(W - WW)]
+    p0, p1, pb, amps = gd.power_spectrum_fft_sharded(
+        lambda i: series[i], l, ops.rfft, lambda *parts: ops.power_spectrum_from_parts(*parts, want_amps=True))
+    q0, q1, qb, qamps = ops.power_spectrum_fft(d(W), d(WW), d(S), d(Wb), d(WbWb), d(B), l, want_amps=True)
+    nk = l // 4 + 1
+    f = [np.fft.rfft(x, n=l) for x in (W - S, Wb - B, WW, WbWb, W - WW)]
+    r0, r1, rb = orc.power_spectrum_from_parts(f[0][:nk], f[1][:nk], f[2][::2], f[3][::2], f[4][::2])
+    for got, fused, ref in ((p0, q0, r0), (p1, q1, r1), (pb, qb, rb)):
+        got, fused = got.cpu().numpy(), fused.cpu().numpy()
+        sc = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-9 * sc and np.abs(got - fused).max() <= 1e-9 * sc
+    assert np.allclose(amps.cpu().numpy()[:, 1:], qamps.cpu().numpy()[:, 1:], rtol=1e-7, atol=1e-12)
