@@ -485,6 +485,31 @@ def run_rank(args):
         del cnt, W, WW, S, B, Wb, WbWb
         torch.cuda.empty_cache()
 
+        # multi-source batch (the C5 shape at 16 of its 1000 sources): C1 lists (1e6 photons, daily
+        # cells) of 16 sources binned into one batch (one wait for the device) and fitted by one launch
+        nsrc = 16
+        srcs = []
+        for k in range(nsrc):
+            ss = synth.synth(1_000_000, years=args.years, seed=1000 + k)
+            srcs.append(core.Data(ss['ti'], ss['we'], ss['TSTART'], ss['TSTOP'], ss['LIVETIME'], ss['exposure'],
+                                  device=dev))
+        for d_ in srcs:
+            d_.get_cells(tcell=86400., use_barycenter=False, quiet=True)      # exposure tables built
+        torch.cuda.synchronize()
+        t0m = time.perf_counter()
+        mb = core.get_cells_batch(srcs, tcell=86400.)
+        torch.cuda.synchronize()
+        t1m = time.perf_counter()
+        mcr = mb.cells.ranges()
+        ops.cell_fit(mcr)
+        m_ms = event_time_ms(lambda i: ops.cell_fit(mcr), 10)
+        extra['multi_source'] = dict(sources=nsrc, photons_per_source=1_000_000, cells=int(mcr.ncell),
+                                     binning_batch_ms=(t1m - t0m) * 1e3, fit_ms=m_ms,
+                                     sources_per_s_fit=nsrc / (m_ms * 1e-3),
+                                     sources_per_s_binning_and_fit=nsrc / (t1m - t0m + m_ms * 1e-3))
+        del srcs, mb, mcr
+        torch.cuda.empty_cache()
+
         # Bayesian Blocks at the C1 shape: ten years of daily cells from the same photons
         bcells = data0.get_cells(tcell=86400., use_barycenter=False, quiet=True)
         bcll = core.CellsLogLikelihood(bcells)

@@ -1362,6 +1362,64 @@ class Data(object):
         return CellBatch(we, ti, lo, hi, starts, stops, sexp, bexp)
 
 
+class SourceBatch(object):
+    """The cells of many sources as ONE device-resident list (multi-source batches: a
+    thousand sky positions, each with its own photon list, exposure table and S, B, E;
+    per source this is what Data.get_cells(...) returns, reference core.py:1958-2206).
+
+    cells         CellBatch over the concatenated photon lists (cells of source 0 first)
+    source        int64 device tensor, the source of every cell
+    cell_offsets  host array [nsource + 1]: cells[cell_offsets[k]:cell_offsets[k + 1]]
+                  are the cells of source k, in time order
+
+    One fit launch serves all sources: ops.cell_fit(batch.cells.ranges()), or
+    CellsLogLikelihood(batch.cells) for profiles and light curves; split(rows) cuts a
+    per-cell result into the per-source pieces."""
+
+    def __init__(self, cells, source, cell_offsets):
+        self.cells, self.source, self.cell_offsets = cells, source, cell_offsets
+
+    def __len__(self):
+        return len(self.cell_offsets) - 1
+
+    def split(self, rows):
+        """Per-source pieces of an array or tensor with one entry (or row) per cell."""
+        o = self.cell_offsets
+        return [rows[int(o[k]):int(o[k + 1])] for k in range(len(o) - 1)]
+
+
+def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True):
+    """Data.get_cells(tstart, tstop, tcell, use_barycenter=False) for every Data object of
+    `sources`, as one SourceBatch.  Every source is binned on its own edges and exposure
+    table; the zero-exposure cells of all of them are then dropped by ONE selection, so the
+    host waits for the device once per batch, not once per source (a thousand sources at
+    45 us a launch would otherwise be bound by those waits)."""
+    if tcell is None:
+        raise ValueError('get_cells_batch needs a cell length')
+    if not sources:
+        raise ValueError('no sources')
+    dev = sources[0].device
+    per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=False,
+                       use_barycenter=False, quiet=quiet) for d in sources]
+    nph = np.array([b.we.numel() for b in per], dtype=np.int64)
+    ncl = np.array([len(b) for b in per], dtype=np.int64)
+    poff = np.concatenate([[0], np.cumsum(nph)])
+    cat = lambda name: torch.cat([getattr(b, name) for b in per])
+    we, ti = cat('we'), cat('ti')
+    shift = torch.repeat_interleave(torch.from_numpy(poff[:-1]).to(dev), torch.from_numpy(ncl).to(dev))
+    lo, hi = cat('lo') + shift, cat('hi') + shift
+    starts, stops, sexp, bexp = cat('starts'), cat('stops'), cat('sexp'), cat('bexp')
+    source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
+    if trim_zero_exposure:
+        # a cell has exposure exactly when it has source exposure (sexp = S / E * exp, S > 0)
+        keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch
+        g = lambda x: ops.gather(x.contiguous(), keep)
+        lo, hi, starts, stops, sexp, bexp, source = g(lo), g(hi), g(starts), g(stops), g(sexp), g(bexp), g(source)
+        ncl = torch.bincount(source, minlength=len(per)).cpu().numpy()
+    cells = CellBatch(we, ti, lo.contiguous(), hi.contiguous(), starts, stops, sexp, bexp)
+    return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
+
+
 class PhaseData(object):
     """Pulse phases instead of times, exposure ignored (reference core.py:2319-2386).
     Constructed from arrays of phases in [0, 1) and weights (the reference reads

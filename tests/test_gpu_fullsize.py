@@ -218,3 +218,77 @@ def test_c3_power_spectrum_matches_numpy_transforms():
         assert np.array_equal(np.isfinite(got), fin), nm
         tol = RTOL * np.maximum(np.abs(ref[fin]), 1e-3 * np.abs(ref[fin]).max())
         assert (np.abs(got[fin] - ref[fin]) <= tol).all(), (nm, np.abs(got[fin] - ref[fin]).max())
+
+
+def test_multi_source_batch_matches_the_oracle_cell_for_cell():
+    """Eight sources of 1e5 photons (the shape of the multi-source job at a ten-thousandth of
+    its size): one batch, one selection, one fit launch; every cell of every source against
+    the oracle's binning, get_max and get_ts; and the sources dealt over two ranks
+    (dist.source_shard) give the same numbers as the single batch."""
+    from godot_amd import core, ops, synth
+    from godot_amd import dist as gd
+    dev = torch.device('cuda:0')
+    nsrc, tcell = 8, 3600.
+    raw = [synth.synth(100_000, years=1.0, seed=1000 + k) for k in range(nsrc)]
+    for k, s in enumerate(raw):                 # sources differ in brightness, not only in photons
+        s['S'] *= 1.0 + 0.1 * k
+    datas = []
+    for s in raw:
+        d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=dev)
+        d.S, d.B = s['S'], s['B']               # the totals are attributes, as in the reference (core.py:1583-1585)
+        datas.append(d)
+    batch = core.get_cells_batch(datas, tcell=tcell)
+    assert len(batch) == nsrc
+    alpha, ts, flags = ops.cell_fit(batch.cells.ranges())
+    assert not (flags.cpu().numpy() & 0x10).any()
+    alpha, ts = alpha.cpu().numpy(), ts.cpu().numpy()
+    lo, hi = batch.cells.lo.cpu().numpy(), batch.cells.hi.cpu().numpy()
+    ncmp = 0
+    with np.errstate(all='ignore'):
+        for k, s in enumerate(raw):
+            b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], s['S'],
+                              s['B'], s['E'], tcell=tcell)
+            c0, c1 = int(batch.cell_offsets[k]), int(batch.cell_offsets[k + 1])
+            assert c1 - c0 == len(b['counts'])
+            assert np.array_equal(hi[c0:c1] - lo[c0:c1], b['counts'])
+            assert np.array_equal(batch.cells.starts[c0:c1].cpu().numpy(), b['starts'])
+            assert np.array_equal(batch.cells.sexp[c0:c1].cpu().numpy(), b['sexp'])
+            for i, cl in enumerate(orc.cells_from_bins(b)):
+                a = cl.get_max()
+                t = cl.get_ts(a)
+                sc = max(1.0, np.abs(np.log1p(-cl.we)).sum())
+                assert abs(alpha[c0 + i] - a) <= 1e-9 * max(1, abs(a)), (k, i, alpha[c0 + i], a)
+                assert abs(ts[c0 + i] - t) <= 1e-9 * max(sc, abs(t)), (k, i, ts[c0 + i], t)
+                ncmp += 1
+    assert ncmp == len(alpha) and ncmp > 30000
+    # two ranks' worth of sources
+    pieces = batch.split(alpha)
+    for rank in range(2):
+        mine = gd.source_shard(nsrc, rank, 2)
+        sub = core.get_cells_batch([datas[k] for k in mine], tcell=tcell)
+        a2, _, _ = ops.cell_fit(sub.cells.ranges())
+        for got, k in zip(sub.split(a2.cpu().numpy()), mine):
+            assert np.allclose(got, pieces[k], rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_c1_raw_light_curve_at_full_size():
+    """C1 as stated: 1e6 photons (seed 7), ten years, one-day cells; binning, profiles and the
+    raw light curve of all 3 652 cells against the oracle."""
+    from godot_amd import core, synth
+    s = synth.synth(1_000_000, years=10.0, seed=7)
+    d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'],
+                  device=torch.device('cuda:0'))
+    cells = d.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+    lc = core.CellsLogLikelihood(cells).get_raw_lightcurve()
+    b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], s['S'], s['B'],
+                      s['E'], tcell=86400.)
+    assert len(cells) == len(b['counts']) and len(cells) >= 3652
+    assert np.array_equal((cells.hi - cells.lo).cpu().numpy(), b['counts'])
+    clls = orc.cells_from_bins(b)
+    with np.errstate(all='ignore'):
+        dom, cod = orc.cells_logpdf(clls)
+        ref = orc.raw_lightcurve(clls, b['starts'], b['stops'], dom, cod)
+    scale = np.maximum(np.abs(ref), 1.0)
+    scale[:, 5] = np.maximum(scale[:, 5], [np.abs(np.log1p(-c.we)).sum() for c in clls])
+    assert np.nanmax(np.abs(lc - ref) / scale) < 1e-9
+    assert np.array_equal(np.isnan(lc), np.isnan(ref))
