@@ -297,9 +297,10 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     constexpr int SLOTS = L * R;
     constexpr int BOUNCE = 52 * R;             // photons in the wavefront's LDS slice
     constexpr int NLOAD = (BOUNCE + 63) / 64;
+    constexpr int NWIDE = (BOUNCE + 127) / 128;   // rows of 128 photons: 16 bytes a lane
     using GC = GroupCell<L, R>;
 
-    __shared__ double sb[BOUNCE + SLOTS];
+    __shared__ __align__(16) double sb[NWIDE * 128 + SLOTS];
 
     const int lane = threadIdx.x;
     const int q = lane % L, ci = lane / L;
@@ -328,7 +329,10 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     const int64_t next_lo = __shfl_down((long long)lo, L, WAVE);
     bool link_ok = !bad;
     if (have && !bad && ci + 1 < nvalid) link_ok = (next_lo == hi);
-    const int64_t base = readlane_i64(lo, 0);
+    const int64_t first = readlane_i64(lo, 0);
+    // the LDS copy begins on a 16-byte boundary of the weights, one photon before the run if
+    // need be, so that its rows can be loaded 16 bytes a lane
+    const int64_t base = first - (int64_t)((((uintptr_t)p.we >> 3) + (uintptr_t)first) & 1);
     const int64_t end = readlane_i64(hi, (nvalid - 1) * L);
     const bool lds_ok = __all(link_ok ? 1 : 0) && (end - base) <= BOUNCE;
     const int span = lds_ok ? (int)(end - base) : 0;
@@ -336,32 +340,42 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     GC gc;
     if (lds_ok) {
         if (span > 0) {
-            double v[NLOAD];
-            if (base + NLOAD * 64 <= p.nph) {
-                // whole 64-photon rows, the last one possibly past the run (never past the array)
-                const double *vp = p.we + base + lane;
+            if (base >= 0 && base + NWIDE * 128 <= p.nph) {
+                // whole 128-photon rows, the last ones possibly past the run (never past the
+                // array); rows past the run hold zeros: stored all the same, never read as photons
+                const double2 *vp = reinterpret_cast<const double2 *>(p.we + base) + lane;
+                double2 v[NWIDE];
 #pragma unroll
-                for (int u = 0; u < NLOAD; ++u) {
-                    v[u] = 0.0;
-                    if (__builtin_expect(u * 64 < span, 1)) v[u] = vp[u * 64];
+                for (int u = 0; u < NWIDE; ++u) {
+                    v[u] = double2{0.0, 0.0};
+                    if (__builtin_expect(u * 128 < span, 1)) v[u] = vp[u * 64];
                 }
+                if (swap) {
+#pragma unroll
+                    for (int u = 0; u < NWIDE; ++u) v[u] = double2{1.0 - v[u].x, 1.0 - v[u].y};
+                }
+                double2 *sb2 = reinterpret_cast<double2 *>(sb);
+#pragma unroll
+                for (int u = 0; u < NWIDE; ++u) sb2[u * 64 + lane] = v[u];
             } else {
+                // the ends of the array: 8 bytes a lane, indices kept inside it
+                double v[NLOAD];
 #pragma unroll
                 for (int u = 0; u < NLOAD; ++u) {
                     const int k = u * 64 + lane;
+                    const int64_t i = base + (k < span ? k : span - 1);
                     v[u] = 0.0;
-                    if (u * 64 < span) v[u] = p.we[base + (k < span ? k : span - 1)];
+                    if (u * 64 < span) v[u] = p.we[i < 0 ? 0 : i];
                 }
-            }
-            if (swap) {
+                if (swap) {
 #pragma unroll
-                for (int u = 0; u < NLOAD; ++u) v[u] = 1.0 - v[u];
-            }
-            // rows past the run hold zeros: stored all the same, never read as photons
+                    for (int u = 0; u < NLOAD; ++u) v[u] = 1.0 - v[u];
+                }
 #pragma unroll
-            for (int u = 0; u < NLOAD; ++u) {
-                const int k = u * 64 + lane;
-                if (u < NLOAD - 1 || k < BOUNCE) sb[k] = v[u];
+                for (int u = 0; u < NLOAD; ++u) {
+                    const int k = u * 64 + lane;
+                    if (u < NLOAD - 1 || k < BOUNCE) sb[k] = v[u];
+                }
             }
         }
         // the slice belongs to this wavefront alone and LDS serves a wavefront's
