@@ -258,7 +258,10 @@ __global__ void pack_kernel(PackBatch pb, int64_t N, cplx *z);
 // content of `a`, or, with `pack`, the real series it describes (batch <= 3):
 // long transforms form the complex input inside their first pass, short ones
 // pack it into `a` first.
-cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st, const PackBatch *pack = nullptr)
+// With last_radix (N >= 256 * last_radix, N / (256 * last_radix) <= 256) the passes are
+// radix 256, what is left, last_radix, and the last one is NOT run: the caller does it.
+cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st, const PackBatch *pack = nullptr,
+              int last_radix = 0)
 {
     int lg = 0;
     while (((int64_t)1 << lg) < N) ++lg;
@@ -318,6 +321,13 @@ cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st, const Pack
         src = dst;
         dst = t;
     };
+    if (last_radix) {
+        launch_fused(16, true);
+        const int64_t mid = N / 256 / last_radix;
+        if (mid >= 32) launch_fused((int)(mid / 16), false);
+        else if (mid > 1) launch((int)mid);
+        return src;
+    }
     if (lg >= 12) {
         // radix-256 passes fused through LDS (one HBM round trip each), then what
         // is left of log2 N: up to four bits as a plain pass, five to seven as a
@@ -343,17 +353,23 @@ __global__ void pack_kernel(PackBatch pb, int64_t N, cplx *z)
     z[(int64_t)blockIdx.y * N + n] = cplx{series_folded(p, 2 * n), series_folded(p, 2 * n + 1)};
 }
 
+// X[k] of the real transform of length 2N from zk = Z[k], zn = Z[N - k] of the packed
+// transform and w = exp(-2 pi i k / (2N))
+__device__ __forceinline__ cplx unpack_pair(cplx zk, cplx zn, cplx w)
+{
+    cplx e = cplx{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};     // (Z[k] + conj Z[N-k]) / 2
+    cplx o = cplx{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};    // (Z[k] - conj Z[N-k]) / (2i)
+    return e + cmul(w, o);
+}
+
 // X[k] of the real transform of length 2N from the packed transform Z (length N)
 __device__ __forceinline__ cplx unpack_bin(const cplx *Z, int64_t N, int64_t k)
 {
     cplx zk = Z[k == N ? 0 : k];
     cplx zn = Z[k == 0 ? 0 : N - k];
-    cplx e = cplx{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};     // (Z[k] + conj Z[N-k]) / 2
-    cplx o = cplx{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};    // (Z[k] - conj Z[N-k]) / (2i)
     double x = -(double)k / (double)(2 * N);
     x -= rint(x);
-    cplx w = expi_cycles(x);
-    return e + cmul(w, o);
+    return unpack_pair(zk, zn, expi_cycles(x));
 }
 
 __global__ void unpack_kernel(const cplx *Z, int64_t N, int64_t nout, cplx *X)
@@ -361,6 +377,50 @@ __global__ void unpack_kernel(const cplx *Z, int64_t N, int64_t nout, cplx *X)
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nout) return;
     X[k] = unpack_bin(Z, N, k);
+}
+
+// The estimators of one frequency bin (core.py:2697-2741) from the cosine and sine
+// sums of the two first-moment series, the zero-frequency values S2, B2, SB of the three
+// second-moment series and the real parts g3, g4, g5 of their bins 2k.
+__device__ __forceinline__ void ps_estimators(int64_t k, int64_t nk, double WmS_cos, double WmS_sin,
+                                              double WbmB_cos, double WbmB_sin, double S2, double B2, double SB,
+                                              double g3, double g4, double g5, double *p0, double *p1,
+                                              double *pb, double *amps)
+{
+    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
+    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
+    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
+    if (k == 0) {
+        WW_sin = 1.;
+        WbWb_sin = 1.;
+    }
+    double a_cos0 = WmS_cos / WW_cos;
+    double a_sin0 = WmS_sin / WW_sin;
+    double b_cos0 = WbmB_cos / WbWb_cos;
+    double b_sin0 = WbmB_sin / WbWb_sin;
+    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
+    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
+    if (k == 0) den_sin = 0.;
+    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
+    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
+    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
+    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
+    if (amps) {
+        amps[0 * nk + k] = a_cos;
+        amps[1 * nk + k] = a_sin;
+        amps[2 * nk + k] = b_cos;
+        amps[3 * nk + k] = b_sin;
+        amps[4 * nk + k] = a_cos0;
+        amps[5 * nk + k] = a_sin0;
+        amps[6 * nk + k] = b_cos0;
+        amps[7 * nk + k] = b_sin0;
+    }
+    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
+    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
+    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
+    if (p0) p0[k] = dl_nobg;
+    if (p1) p1[k] = dl - dl_null;
+    if (pb) pb[k] = dl_null;
 }
 
 // ---- power_spectrum_fft epilogue (core.py:2683-2741) -----------------------
@@ -382,40 +442,7 @@ __global__ void ps_epilogue_kernel(const cplx *Z1, int64_t N1, const cplx *Z2, i
     double g3 = unpack_bin(Z2, N2, k).x;            // Re rfft(WW)[2k]
     double g4 = unpack_bin(Z2 + N2, N2, k).x;       // Re rfft(WbWb)[2k]
     double g5 = unpack_bin(Z2 + 2 * N2, N2, k).x;   // Re rfft(W-WW)[2k]
-    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
-    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
-    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
-    if (k == 0) {
-        WW_sin = 1.;
-        WbWb_sin = 1.;
-    }
-    double a_cos0 = WmS_cos / WW_cos;
-    double a_sin0 = WmS_sin / WW_sin;
-    double b_cos0 = WbmB_cos / WbWb_cos;
-    double b_sin0 = WbmB_sin / WbWb_sin;
-    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
-    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
-    if (k == 0) den_sin = 0.;
-    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
-    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
-    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
-    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
-    if (amps) {
-        amps[0 * nk + k] = a_cos;
-        amps[1 * nk + k] = a_sin;
-        amps[2 * nk + k] = b_cos;
-        amps[3 * nk + k] = b_sin;
-        amps[4 * nk + k] = a_cos0;
-        amps[5 * nk + k] = a_sin0;
-        amps[6 * nk + k] = b_cos0;
-        amps[7 * nk + k] = b_sin0;
-    }
-    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
-    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
-    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
-    if (p0) p0[k] = dl_nobg;
-    if (p1) p1[k] = dl - dl_null;
-    if (pb) pb[k] = dl_null;
+    ps_estimators(k, nk, WmS_cos, WmS_sin, WbmB_cos, WbmB_sin, S2, B2, SB, g3, g4, g5, p0, p1, pb, amps);
 }
 
 // The same estimators from the five transforms handed over one by one, each cut to
@@ -433,40 +460,214 @@ __global__ void ps_epilogue_parts_kernel(const cplx *F1, const cplx *F2, const c
     double WbmB_cos = f2.x, WbmB_sin = -f2.y;
     const double S2 = G3[0].x, B2 = G4[0].x, SB = G5[0].x;
     const double g3 = G3[k].x, g4 = G4[k].x, g5 = G5[k].x;
-    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
-    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
-    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
-    if (k == 0) {
-        WW_sin = 1.;
-        WbWb_sin = 1.;
+    ps_estimators(k, nk, WmS_cos, WmS_sin, WbmB_cos, WbmB_sin, S2, B2, SB, g3, g4, g5, p0, p1, pb, amps);
+}
+
+// ---- last Stockham pass of the five transforms + split + estimators in one kernel ------
+// For N1 = 256 S (first-moment transforms) and N2 = 128 S (second-moment transforms) the last
+// pass of radix R = 256 or 128 forms Z[j + q S], q < R, from column j of the data before it.
+// Bin k = j + q S of the real transform needs Z[k] and Z[N - k], and
+// N - k = (S - j) + (R - 1 - q) S: the partner lives in column S - j.  A workgroup therefore
+// takes eight columns j = 8 w + c and their eight partners S - j, runs the last pass of each of
+// the five series on those sixteen columns (the two radix-16 stages of stockham_fused_kernel),
+// leaves the sixteen transformed columns in LDS as [q][column], and every thread picks the pairs
+// of its eight bins from there.  Only the three real parts of the second-moment bins and the
+// first of the two first-moment bins wait in registers for the estimators, which are evaluated
+// as the last series arrives; the transforms themselves are never written to memory.
+// Columns 0 and S/2 are their own partners ((R - q) mod R and R - 1 - q in the same column):
+// they are taken by one more workgroup.  The bin k = l/4 (column 0, q = 128) and the
+// zero-frequency values that every bin needs come from ps_dc_kernel.
+
+// One series: the radix-(16 A) butterflies of sixteen columns, result in lds[q * 16 + column].
+template <int A>
+__device__ __forceinline__ void final_pass_columns(const cplx *__restrict__ src, int64_t S, int64_t jc,
+                                                   cplx *lds, int tid)
+{
+    constexpr int R = A * 16;
+    const int t = tid >> 4, col = tid & 15;
+    cplx v[A];
+    // the arithmetic on the pairs of the series before stays ahead of this series' loads:
+    // pushed behind them, the pairs wait in registers the kernel does not have
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < A; ++m) v[m] = src[jc + (int64_t)(t + 16 * m) * S];
+    // The twiddles are the same for every series of one radix; kept across the series they
+    // would hold over a hundred registers, so they are formed anew from an angle the compiler
+    // cannot tell from the last one.
+    double th = -(double)jc / (double)(S * R);
+    double tr = -(double)t / (double)R;
+    asm volatile("" : "+v"(th), "+v"(tr));
+    {
+        // x_r *= exp(-2 pi i jc r / (S R)), r = t + 16 m
+        double xt = th * (double)t, xb = th * 16.0;
+        xt -= rint(xt);
+        xb -= rint(xb);
+        const cplx wt = expi_cycles(xt);
+        cplx pw[A];
+        pw[0] = cplx{1.0, 0.0};
+        pw[1] = expi_cycles(xb);
+#pragma unroll
+        for (int m = 2; m < A; ++m) pw[m] = cmul(pw[m / 2], pw[m - m / 2]);
+        v[0] = cmul(v[0], wt);
+#pragma unroll
+        for (int m = 1; m < A; ++m) v[m] = cmul(v[m], cmul(wt, pw[m]));
     }
-    double a_cos0 = WmS_cos / WW_cos;
-    double a_sin0 = WmS_sin / WW_sin;
-    double b_cos0 = WbmB_cos / WbWb_cos;
-    double b_sin0 = WbmB_sin / WbWb_sin;
-    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
-    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
-    if (k == 0) den_sin = 0.;
-    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
-    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
-    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
-    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
-    if (amps) {
-        amps[0 * nk + k] = a_cos;
-        amps[1 * nk + k] = a_sin;
-        amps[2 * nk + k] = b_cos;
-        amps[3 * nk + k] = b_sin;
-        amps[4 * nk + k] = a_cos0;
-        amps[5 * nk + k] = a_sin0;
-        amps[6 * nk + k] = b_cos0;
-        amps[7 * nk + k] = b_sin0;
+    dft<A>(v);
+    {
+        cplx pw[A];
+        pw[0] = cplx{1.0, 0.0};
+        pw[1] = expi_cycles(tr);
+#pragma unroll
+        for (int q = 2; q < A; ++q) pw[q] = cmul(pw[q / 2], pw[q - q / 2]);
+#pragma unroll
+        for (int q = 1; q < A; ++q) v[q] = cmul(v[q], pw[q]);
     }
-    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
-    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
-    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
-    if (p0) p0[k] = dl_nobg;
-    if (p1) p1[k] = dl - dl_null;
-    if (pb) pb[k] = dl_null;
+    __syncthreads();   // the pairs of the series before this one have been read
+#pragma unroll
+    for (int q = 0; q < A; ++q) lds[(q * 16 + t) * 16 + col + q] = v[q];
+    __syncthreads();
+    const int u = tid >> 4;
+    cplx z[16];
+    if (u < A) {
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) z[tt] = lds[(u * 16 + tt) * 16 + col + u];
+        dft<16>(z);
+    }
+    __syncthreads();
+    if (u < A) {
+#pragma unroll
+        for (int h = 0; h < 16; ++h) lds[(u + A * h) * 16 + col] = z[h];
+    }
+    __syncthreads();
+}
+
+struct FinalArgs {
+    const cplx *y1;   // [2][N1] before the last pass
+    const cplx *y2;   // [3][N2] before the last pass
+    int64_t S;        // N1 / 256 = N2 / 128
+    const double *dc; // S2, B2, SB
+    double *p0, *p1, *pb, *amps;
+    int64_t nk;
+};
+
+__global__ __launch_bounds__(256, 2) void ps_final_kernel(FinalArgs a)
+{
+    __shared__ cplx lds[16 * 256 + 16];
+    const int tid = threadIdx.x;
+    const int col = tid & 15, qi = tid >> 4;
+    const int64_t S = a.S, N1 = 256 * S, N2 = 128 * S;
+    const int64_t ntile = S / 16;
+    const bool special = (int64_t)blockIdx.x == ntile;
+    // consecutive tiles share cache lines of the partner columns: keep them on one XCD
+    // (workgroups are dealt to the eight XCDs in turn)
+    int64_t w = blockIdx.x;
+    if (!special && (ntile & 7) == 0) w = (w & 7) * (ntile >> 3) + (w >> 3);
+    int64_t jc;        // the column of this lane
+    bool writes;       // whether its bins are this workgroup's to write
+    if (special) {
+        jc = col < 8 ? 0 : S / 2;
+        writes = (col & 7) == 0;
+    } else {
+        const int64_t ja = 8 * w + (col & 7);
+        jc = col < 8 ? ja : S - ja;
+        writes = ja != 0;
+        if (jc == S) jc = 0;   // partner of column 0: computed, not used
+    }
+    const int mcol = special ? col : (col ^ 8);
+    const bool wrap = special && col < 8;   // column 0: partner of q is (R - q) mod R
+    // exp(-2 pi i k / l) for k = jc + (qi + 16 h) S steps by exp(-2 pi i / 32) in h
+    const cplx w0 = expi_cycles(-(double)(jc + (int64_t)qi * S) / (double)(2 * N1));
+    const cplx rho{0.98078528040323044913, -0.19509032201612826785};
+    double g3[8], g4[8], g5[8];
+    cplx f1[8];
+
+    auto second_moment = [&](const cplx *src, double (&g)[8]) {
+        final_pass_columns<8>(src, S, jc, lds, tid);
+        cplx w1 = w0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int q = qi + 16 * h;
+            const int mq = wrap ? ((128 - q) & 127) : 127 - q;
+            const cplx zk = lds[q * 16 + col], zn = lds[mq * 16 + mcol];
+            const cplx w2 = cmul(w1, w1);   // exp(-2 pi i k / (2 N2))
+            const double ox = 0.5 * (zk.y + zn.y), oy = -0.5 * (zk.x - zn.x);
+            g[h] = 0.5 * (zk.x + zn.x) + fma(w2.x, ox, -(w2.y * oy));
+            asm volatile("" : "+v"(g[h]));   // formed here, not where it is used: the pair would wait
+            w1 = cmul(w1, rho);
+        }
+    };
+    second_moment(a.y2, g3);
+    second_moment(a.y2 + N2, g4);
+    second_moment(a.y2 + 2 * N2, g5);
+
+    final_pass_columns<16>(a.y1, S, jc, lds, tid);
+    {
+        cplx w1 = w0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int q = qi + 16 * h;
+            const int mq = wrap ? ((256 - q) & 255) : 255 - q;
+            f1[h] = unpack_pair(lds[q * 16 + col], lds[mq * 16 + mcol], w1);
+            asm volatile("" : "+v"(f1[h].x), "+v"(f1[h].y));
+            w1 = cmul(w1, rho);
+        }
+    }
+    final_pass_columns<16>(a.y1 + N1, S, jc, lds, tid);
+    const double S2 = a.dc[0], B2 = a.dc[1], SB = a.dc[2];
+    cplx w1 = w0;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int q = qi + 16 * h;
+        const int mq = wrap ? ((256 - q) & 255) : 255 - q;
+        const cplx f2 = unpack_pair(lds[q * 16 + col], lds[mq * 16 + mcol], w1);
+        w1 = cmul(w1, rho);
+        if (writes) {
+            const int64_t k = jc + (int64_t)q * S;
+            ps_estimators(k, a.nk, f1[h].x, -f1[h].y, f2.x, -f2.y, S2, B2, SB, g3[h], g4[h], g5[h], a.p0, a.p1,
+                          a.pb, a.amps);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one bin at a time: interleaving them costs registers
+    }
+}
+
+// What ps_final_kernel does not reach: the zero-frequency values S2, B2, SB of the
+// second-moment series (sum of column 0 before the last pass: real + imaginary part of
+// Z[0]) and the bin k = l/4, made of Z1[N1/2] (alternating sum of column 0) and Z2[0].
+__global__ __launch_bounds__(256) void ps_dc_kernel(FinalArgs a, double *dc)
+{
+    __shared__ double red[10][256];
+    const int r = threadIdx.x;
+    const int64_t S = a.S, N1 = 256 * S, N2 = 128 * S;
+    const double sg = (r & 1) ? -1.0 : 1.0;
+    const cplx u1 = a.y1[(int64_t)r * S], u2 = a.y1[N1 + (int64_t)r * S];
+    red[0][r] = sg * u1.x;
+    red[1][r] = sg * u1.y;
+    red[2][r] = sg * u2.x;
+    red[3][r] = sg * u2.y;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        cplx v{0.0, 0.0};
+        if (r < 128) v = a.y2[s * N2 + (int64_t)r * S];
+        red[4 + 2 * s][r] = v.x;
+        red[5 + 2 * s][r] = v.y;
+    }
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (r < half)
+#pragma unroll
+            for (int i = 0; i < 10; ++i) red[i][r] += red[i][r + half];
+        __syncthreads();
+    }
+    if (r == 0) {
+        const double S2 = red[4][0] + red[5][0], B2 = red[6][0] + red[7][0], SB = red[8][0] + red[9][0];
+        dc[0] = S2;
+        dc[1] = B2;
+        dc[2] = SB;
+        // k = l/4: F = conj Z1[N1/2]; even bins of the second moments at k = N2: Re Z2[0] - Im Z2[0]
+        ps_estimators(a.nk - 1, a.nk, red[0][0], red[1][0], red[2][0], red[3][0], S2, B2, SB,
+                      red[4][0] - red[5][0], red[6][0] - red[7][0], red[8][0] - red[9][0], a.p0, a.p1, a.pb,
+                      a.amps);
+    }
 }
 
 // power_spectrum_simple epilogue (core.py:2766-2782)
@@ -599,38 +800,7 @@ __global__ void ps_epilogue_full_kernel(const cplx *F, int64_t fstride, int64_t 
     double WbmB_cos = f2.x, WbmB_sin = -f2.y;
     double S2 = F[2 * fstride].x, B2 = F[3 * fstride].x, SB = F[4 * fstride].x;
     double g3 = F[2 * fstride + 2 * k].x, g4 = F[3 * fstride + 2 * k].x, g5 = F[4 * fstride + 2 * k].x;
-    double WW_cos = 0.5 * (S2 + g3), WW_sin = 0.5 * (S2 - g3);
-    double WbWb_cos = 0.5 * (B2 + g4), WbWb_sin = 0.5 * (B2 - g4);
-    double WWb_cos = 0.5 * (SB + g5), WWb_sin = 0.5 * (SB - g5);
-    if (k == 0) {
-        WW_sin = 1.;
-        WbWb_sin = 1.;
-    }
-    double a_cos0 = WmS_cos / WW_cos, a_sin0 = WmS_sin / WW_sin;
-    double b_cos0 = WbmB_cos / WbWb_cos, b_sin0 = WbmB_sin / WbWb_sin;
-    double den_cos = 1. / (WW_cos * WbWb_cos - WWb_cos * WWb_cos);
-    double den_sin = 1. / (WW_sin * WbWb_sin - WWb_sin * WWb_sin);
-    if (k == 0) den_sin = 0.;
-    double a_cos = (WbWb_cos * WmS_cos - WWb_cos * WbmB_cos) * den_cos;
-    double a_sin = (WbWb_sin * WmS_sin - WWb_sin * WbmB_sin) * den_sin;
-    double b_cos = (WW_cos * WbmB_cos - WWb_cos * WmS_cos) * den_cos;
-    double b_sin = (WW_sin * WbmB_sin - WWb_sin * WmS_sin) * den_sin;
-    if (amps) {
-        amps[0 * nk + k] = a_cos;
-        amps[1 * nk + k] = a_sin;
-        amps[2 * nk + k] = b_cos;
-        amps[3 * nk + k] = b_sin;
-        amps[4 * nk + k] = a_cos0;
-        amps[5 * nk + k] = a_sin0;
-        amps[6 * nk + k] = b_cos0;
-        amps[7 * nk + k] = b_sin0;
-    }
-    double dl_null = b_cos0 * WbmB_cos + b_sin0 * WbmB_sin;
-    double dl_nobg = a_cos0 * WmS_cos + a_sin0 * WmS_sin;
-    double dl = a_cos * WmS_cos + a_sin * WmS_sin + b_cos * WbmB_cos + b_sin * WbmB_sin;
-    if (p0) p0[k] = dl_nobg;
-    if (p1) p1[k] = dl - dl_null;
-    if (pb) pb[k] = dl_null;
+    ps_estimators(k, nk, WmS_cos, WmS_sin, WbmB_cos, WbmB_sin, S2, B2, SB, g3, g4, g5, p0, p1, pb, amps);
 }
 
 __global__ void ps_simple_epilogue_full_kernel(const cplx *F, int64_t fstride, int64_t nk, double *dlogl,
@@ -737,10 +907,21 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
     pb2.s[0] = PackArgs{WW, nullptr, n, l / 2};
     pb2.s[1] = PackArgs{WbWb, nullptr, n, l / 2};
     pb2.s[2] = PackArgs{W, WW, n, l / 2};
-    cplx *Z2 = fft_c2c(a2, b2, N2, 3, st, &pb2);
     PackBatch pb1{};
     pb1.s[0] = PackArgs{W, S, n, 0};
     pb1.s[1] = PackArgs{Wb, B, n, 0};
+    if (N1 >= ((int64_t)1 << 16) && N1 <= ((int64_t)1 << 24)) {
+        // the last pass of all five transforms, the split and the estimators in one kernel
+        cplx *Y2 = fft_c2c(a2, b2, N2, 3, st, &pb2, 128);
+        cplx *Y1 = fft_c2c(a1, b1, N1, 2, st, &pb1, 256);
+        double *dc = (double *)(Y2 == a2 ? b2 : a2);   // the buffer the last pass would have written
+        FinalArgs fa{Y1, Y2, N1 / 256, dc, p0, p1, pb, amps, nk};
+        hipLaunchKernelGGL(ps_dc_kernel, dim3(1), dim3(256), 0, st, fa, dc);
+        hipLaunchKernelGGL(ps_final_kernel, dim3((unsigned)(fa.S / 16 + 1)), dim3(256), 0, st, fa);
+        GODOT_LAUNCH_CHECK("godot_power_spectrum_fft");
+        return GODOT_OK;
+    }
+    cplx *Z2 = fft_c2c(a2, b2, N2, 3, st, &pb2);
     cplx *Z1 = fft_c2c(a1, b1, N1, 2, st, &pb1);
     hipLaunchKernelGGL(ps_epilogue_kernel, dim3((unsigned)ceil_div(nk, 256)), dim3(256), 0, st, (const cplx *)Z1,
                        N1, (const cplx *)Z2, N2, nk, p0, p1, pb, amps);
