@@ -475,22 +475,28 @@ __global__ void ps_epilogue_parts_kernel(const cplx *F1, const cplx *F2, const c
 // first of the two first-moment bins wait in registers for the estimators, which are evaluated
 // as the last series arrives; the transforms themselves are never written to memory.
 // Columns 0 and S/2 are their own partners ((R - q) mod R and R - 1 - q in the same column):
-// they are taken by one more workgroup.  The bin k = l/4 (column 0, q = 128) and the
-// zero-frequency values that every bin needs come from ps_dc_kernel.
+// the first workgroup takes both, where the others have column 8 w and its partner.
+// The loads of a series are issued before the pairs of the series before it are worked on.
+// The bin k = l/4 (column 0, q = 128) and the zero-frequency values that every bin needs
+// come from ps_dc_kernel.
+
+template <int A>
+__device__ __forceinline__ void final_pass_load(const cplx *__restrict__ src, int64_t S, int64_t jc, int tid,
+                                                cplx (&v)[A])
+{
+    const int t = tid >> 4;
+#pragma unroll
+    for (int m = 0; m < A; ++m) v[m] = src[jc + (int64_t)(t + 16 * m) * S];
+    // what follows in the program stays behind these loads
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // One series: the radix-(16 A) butterflies of sixteen columns, result in lds[q * 16 + column].
 template <int A>
-__device__ __forceinline__ void final_pass_columns(const cplx *__restrict__ src, int64_t S, int64_t jc,
-                                                   cplx *lds, int tid)
+__device__ __forceinline__ void final_pass_columns(cplx (&v)[A], int64_t S, int64_t jc, cplx *lds, int tid)
 {
     constexpr int R = A * 16;
     const int t = tid >> 4, col = tid & 15;
-    cplx v[A];
-    // the arithmetic on the pairs of the series before stays ahead of this series' loads:
-    // pushed behind them, the pairs wait in registers the kernel does not have
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < A; ++m) v[m] = src[jc + (int64_t)(t + 16 * m) * S];
     // The twiddles are the same for every series of one radix; kept across the series they
     // would hold over a hundred registers, so they are formed anew from an angle the compiler
     // cannot tell from the last one.
@@ -502,25 +508,23 @@ __device__ __forceinline__ void final_pass_columns(const cplx *__restrict__ src,
         double xt = th * (double)t, xb = th * 16.0;
         xt -= rint(xt);
         xb -= rint(xb);
-        const cplx wt = expi_cycles(xt);
-        cplx pw[A];
-        pw[0] = cplx{1.0, 0.0};
-        pw[1] = expi_cycles(xb);
+        const cplx step = expi_cycles(xb);
+        cplx tw = expi_cycles(xt);
 #pragma unroll
-        for (int m = 2; m < A; ++m) pw[m] = cmul(pw[m / 2], pw[m - m / 2]);
-        v[0] = cmul(v[0], wt);
-#pragma unroll
-        for (int m = 1; m < A; ++m) v[m] = cmul(v[m], cmul(wt, pw[m]));
+        for (int m = 0; m < A; ++m) {
+            v[m] = cmul(v[m], tw);
+            if (m + 1 < A) tw = cmul(tw, step);
+        }
     }
     dft<A>(v);
     {
-        cplx pw[A];
-        pw[0] = cplx{1.0, 0.0};
-        pw[1] = expi_cycles(tr);
+        const cplx step = expi_cycles(tr);   // W_R^t
+        cplx tw = step;
 #pragma unroll
-        for (int q = 2; q < A; ++q) pw[q] = cmul(pw[q / 2], pw[q - q / 2]);
-#pragma unroll
-        for (int q = 1; q < A; ++q) v[q] = cmul(v[q], pw[q]);
+        for (int q = 1; q < A; ++q) {
+            v[q] = cmul(v[q], tw);
+            if (q + 1 < A) tw = cmul(tw, step);
+        }
     }
     __syncthreads();   // the pairs of the series before this one have been read
 #pragma unroll
@@ -557,32 +561,22 @@ __global__ __launch_bounds__(256, 2) void ps_final_kernel(FinalArgs a)
     const int col = tid & 15, qi = tid >> 4;
     const int64_t S = a.S, N1 = 256 * S, N2 = 128 * S;
     const int64_t ntile = S / 16;
-    const bool special = (int64_t)blockIdx.x == ntile;
     // consecutive tiles share cache lines of the partner columns: keep them on one XCD
     // (workgroups are dealt to the eight XCDs in turn)
     int64_t w = blockIdx.x;
-    if (!special && (ntile & 7) == 0) w = (w & 7) * (ntile >> 3) + (w >> 3);
-    int64_t jc;        // the column of this lane
-    bool writes;       // whether its bins are this workgroup's to write
-    if (special) {
-        jc = col < 8 ? 0 : S / 2;
-        writes = (col & 7) == 0;
-    } else {
-        const int64_t ja = 8 * w + (col & 7);
-        jc = col < 8 ? ja : S - ja;
-        writes = ja != 0;
-        if (jc == S) jc = 0;   // partner of column 0: computed, not used
-    }
-    const int mcol = special ? col : (col ^ 8);
-    const bool wrap = special && col < 8;   // column 0: partner of q is (R - q) mod R
+    if ((ntile & 7) == 0) w = (w & 7) * (ntile >> 3) + (w >> 3);
+    const int64_t ja = 8 * w + (col & 7);
+    const bool selfp = ja == 0;   // tile 0: column 0 and, in place of its partner, column S/2
+    const int64_t jc = col < 8 ? ja : (selfp ? S / 2 : S - ja);   // the column of this lane
+    const int mcol = selfp ? col : (col ^ 8);
+    const bool wrap = selfp && col < 8;   // column 0: partner of q is (R - q) mod R
     // exp(-2 pi i k / l) for k = jc + (qi + 16 h) S steps by exp(-2 pi i / 32) in h
     const cplx w0 = expi_cycles(-(double)(jc + (int64_t)qi * S) / (double)(2 * N1));
     const cplx rho{0.98078528040323044913, -0.19509032201612826785};
     double g3[8], g4[8], g5[8];
     cplx f1[8];
 
-    auto second_moment = [&](const cplx *src, double (&g)[8]) {
-        final_pass_columns<8>(src, S, jc, lds, tid);
+    auto second_moment = [&](double (&g)[8]) {
         cplx w1 = w0;
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
@@ -596,11 +590,19 @@ __global__ __launch_bounds__(256, 2) void ps_final_kernel(FinalArgs a)
             w1 = cmul(w1, rho);
         }
     };
-    second_moment(a.y2, g3);
-    second_moment(a.y2 + N2, g4);
-    second_moment(a.y2 + 2 * N2, g5);
-
-    final_pass_columns<16>(a.y1, S, jc, lds, tid);
+    cplx va[8], vb[8], vc[16], vd[16];
+    final_pass_load<8>(a.y2, S, jc, tid, va);
+    final_pass_columns<8>(va, S, jc, lds, tid);
+    final_pass_load<8>(a.y2 + N2, S, jc, tid, vb);
+    second_moment(g3);
+    final_pass_columns<8>(vb, S, jc, lds, tid);
+    final_pass_load<8>(a.y2 + 2 * N2, S, jc, tid, va);
+    second_moment(g4);
+    final_pass_columns<8>(va, S, jc, lds, tid);
+    final_pass_load<16>(a.y1, S, jc, tid, vc);
+    second_moment(g5);
+    final_pass_columns<16>(vc, S, jc, lds, tid);
+    final_pass_load<16>(a.y1 + N1, S, jc, tid, vd);
     {
         cplx w1 = w0;
 #pragma unroll
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void ps_final_kernel(FinalArgs a)
             w1 = cmul(w1, rho);
         }
     }
-    final_pass_columns<16>(a.y1 + N1, S, jc, lds, tid);
+    final_pass_columns<16>(vd, S, jc, lds, tid);
     const double S2 = a.dc[0], B2 = a.dc[1], SB = a.dc[2];
     cplx w1 = w0;
 #pragma unroll
@@ -621,11 +623,9 @@ __global__ __launch_bounds__(256, 2) void ps_final_kernel(FinalArgs a)
         const int mq = wrap ? ((256 - q) & 255) : 255 - q;
         const cplx f2 = unpack_pair(lds[q * 16 + col], lds[mq * 16 + mcol], w1);
         w1 = cmul(w1, rho);
-        if (writes) {
-            const int64_t k = jc + (int64_t)q * S;
-            ps_estimators(k, a.nk, f1[h].x, -f1[h].y, f2.x, -f2.y, S2, B2, SB, g3[h], g4[h], g5[h], a.p0, a.p1,
-                          a.pb, a.amps);
-        }
+        const int64_t k = jc + (int64_t)q * S;
+        ps_estimators(k, a.nk, f1[h].x, -f1[h].y, f2.x, -f2.y, S2, B2, SB, g3[h], g4[h], g5[h], a.p0, a.p1, a.pb,
+                      a.amps);
         __builtin_amdgcn_sched_barrier(0);   // one bin at a time: interleaving them costs registers
     }
 }
@@ -917,7 +917,7 @@ extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const
         double *dc = (double *)(Y2 == a2 ? b2 : a2);   // the buffer the last pass would have written
         FinalArgs fa{Y1, Y2, N1 / 256, dc, p0, p1, pb, amps, nk};
         hipLaunchKernelGGL(ps_dc_kernel, dim3(1), dim3(256), 0, st, fa, dc);
-        hipLaunchKernelGGL(ps_final_kernel, dim3((unsigned)(fa.S / 16 + 1)), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(ps_final_kernel, dim3((unsigned)(fa.S / 16)), dim3(256), 0, st, fa);
         GODOT_LAUNCH_CHECK("godot_power_spectrum_fft");
         return GODOT_OK;
     }
