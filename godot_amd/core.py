@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._lib import GodotError
 from .scalers import PiecewiseScaler
 
 __all__ = ['Cell', 'PhaseCell', 'cell_from_cells', 'CellBatch', 'CellTimeSeries',
@@ -588,12 +589,22 @@ class CellLogLikelihood(object):
         return ((W - self.S) * t2 + (N - self.B - W) * t1) / (W2 * t2 - t1 ** 2)
 
 
+def _raise_bad_ranges(flags):
+    """A cell whose photon range lies outside the photon arrays (GODOT_F_BAD_RANGE) is a
+    fault of whoever built the ranges, never of the data: no allow_failed_cells hides it."""
+    bad = (flags & 0x80) != 0
+    if bool(bad.any().cpu()):
+        raise GodotError('photon range of cell %d is not inside the photon arrays'
+                         % int(torch.nonzero(bad)[0].cpu()))
+
+
 def _raise_as_reference(flags, allow):
     """The reference fits cell after cell and stops at the first one it cannot fit: a
     ValueError from its root finder when the score has no sign change (core.py:728-739),
     a RecursionError when get_logpdf re-centres without end (core.py:923-929).  The
     kernels mark such cells (GODOT_F_FAILED) and go on; with allow=False the batch call
     then raises what the reference would have."""
+    _raise_bad_ranges(flags)
     if allow:
         return
     bad = (flags & 0x10) != 0
@@ -607,6 +618,7 @@ def _raise_as_reference(flags, allow):
 def _raise_unconverged_beta(flags, allow, alpha=None):
     """get_beta_max raises a ValueError when its restarts run out (reference core.py:816-819);
     the kernels mark such cells GODOT_F_FAILED and go on."""
+    _raise_bad_ranges(flags)
     if allow:
         return
     bad = (flags & 0x10) != 0
@@ -791,6 +803,7 @@ class CellsLogLikelihood(object):
             ts = torch.where((aopt == 0) | (s_eff == 0), torch.zeros_like(ts), ts)
         else:
             aopt, ts, fl = ops.cell_fit(cr, swap=self._swap)
+            _raise_bad_ranges(fl)
             if bool((fl & 0x10).any().cpu()):
                 raise ValueError('f(a) and f(b) must have different signs')
             dom, cod, _ = ops.cell_logpdf(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)

@@ -72,7 +72,7 @@ __device__ __forceinline__ void cell_fit_body(const CellArgs &p, const double *g
         double a = qnan();
         bool at_zero = false, done = true;
         if (bad) {
-            fl = GODOT_F_FAILED;
+            fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
         } else if (fit_attempt_impl<CellData<T, R>, B0>(cd, S, g, b, a, at_zero)) {
             if (at_zero) {
                 a = 0.0;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
         double a0;
         if (bad) {
             a0 = qnan();
-            fl = GODOT_F_FAILED;
+            fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
         } else if (aopt_in) {
             a0 = aopt_in[cell];
         } else {

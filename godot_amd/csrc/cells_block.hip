@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_block_kernel(CellArgs p, 
     int fl = 0;
     double a = qnan(), t = qnan();
     if (b.bad) {
-        fl = GODOT_F_FAILED;
+        fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
     } else {
         a = fit_alpha(cd, b.S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
         if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, b.S, a);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_block_kernel(CellArgs 
     bool ok = !b.bad;
     double aopt = qnan();
     if (b.bad) {
-        fl = GODOT_F_FAILED;
+        fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
     } else if (aopt_in) {
         aopt = aopt_in[cell];
     } else {
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_fit_spread_kernel(CellArgs p,
     int fl = 0;
     double a = qnan(), t = qnan();
     if (s.b.bad) {
-        fl = GODOT_F_FAILED;
+        fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
     } else {
         a = fit_alpha(cd, s.b.S, guess ? guess[cell] : guess0, beta ? beta[cell] : beta0, fl);
         if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, s.b.S, a);
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_spread_kernel(CellArgs
     bool ok = !s.b.bad;
     double aopt = qnan();
     if (s.b.bad) {
-        fl = GODOT_F_FAILED;
+        fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
     } else if (aopt_in) {
         aopt = aopt_in[cell];
     } else {

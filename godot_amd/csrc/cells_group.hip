@@ -410,7 +410,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         b = B0 ? 0.0 : (beta ? beta[cell] : beta0) - 1;
         if (bad) {
             o_t = qnan();
-            o_fl = GODOT_F_FAILED;
+            o_fl = GODOT_F_FAILED | GODOT_F_BAD_RANGE;
             o_full = true;
         } else if (!big) {
             double a;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, co
 
     // state of this lane's cell: 0 = to do, 1 = done, 2 = absent or failed
     int state = (have && !bad) ? 0 : 2;
-    int fl = (have && bad) ? GODOT_F_FAILED : 0;
+    int fl = (have && bad) ? (GODOT_F_FAILED | GODOT_F_BAD_RANGE) : 0;
     double aopt = qnan();
     if (state == 0) {
         if (aopt_in) {

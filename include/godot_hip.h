@@ -51,6 +51,9 @@ extern "C" {
 #define GODOT_F_RETRIED     0x40  /* a very large cell spread over several workgroups was fitted
                                      again by one: the workgroups did not all become resident
                                      together (shared or busy GPU); the result is as good */
+#define GODOT_F_BAD_RANGE   0x80  /* set with GODOT_F_FAILED: the cell's photon range [lo, hi)
+                                     is not inside the photon arrays (a caller's error, not
+                                     a property of the data)                               */
 
 typedef void *godot_stream_t;
 

@@ -155,6 +155,27 @@ def test_bad_ranges_are_flagged_not_read():
     a, fl = a.cpu().numpy(), fl.cpu().numpy()
     assert np.isfinite(a[0]) and np.isnan(a[1:]).all()
     assert (fl[1:] & 0x10).all()
+    # a fault of the caller's, told apart from a cell the data make unfittable, and never
+    # passed over: not even where unfittable cells are allowed
+    assert (fl[1:] & 0x80).all() and not fl[0] & 0x80
+    from godot_amd import core
+    from godot_amd._lib import GodotError
+    for allow in (False, True):
+        with pytest.raises(GodotError):
+            core._raise_as_reference(torch.from_numpy(fl).to(dev), allow)
+    core._raise_as_reference(torch.from_numpy(fl[:1]).to(dev), False)
+    for shape in ((3000,), (40,)):   # one workgroup per cell; lane groups
+        n = shape[0]
+        w2 = torch.rand(2 * n, dtype=torch.float64, device=dev) * 0.9 + 0.05
+        lo2 = torch.tensor([0, n], dtype=torch.int64, device=dev)
+        hi2 = torch.tensor([n, 2 * n + 1], dtype=torch.int64, device=dev)
+        S2 = torch.full((2,), n * 0.5, dtype=torch.float64, device=dev)
+        _, _, f2 = ops.cell_fit(ops.CellRanges(w2, lo2, hi2, S2, S2.clone()))
+        f2 = f2.cpu().numpy()
+        assert f2[1] & 0x80 and f2[1] & 0x10 and not f2[0] & 0x90
+        _, _, f3 = ops.cell_logpdf(ops.CellRanges(w2, lo2, hi2, S2, S2.clone()), npt=50)
+        f3 = f3.cpu().numpy()
+        assert f3[1] & 0x80 and not f3[0] & 0x80
 
 
 @pytest.mark.parametrize('nph,ncell', [(200000, 20000), (200000, 700), (100000, 3)])
