@@ -177,7 +177,10 @@ struct PackBatch {
 // PACKED (with FIRST): the input is not a complex buffer but the real series
 // themselves, z[n] = x[2n] + i x[2n+1] formed while loading; samples past the
 // end of a zero-padded series cost no memory traffic.
-template <int A, bool FIRST, bool PACKED>
+// STREAM: the results are written with non-temporal stores (for buffers that the
+// last-level cache cannot hold until the next pass reads them; a template parameter
+// because the compiler merges the two stores of a run-time choice into plain ones).
+template <int A, bool FIRST, bool PACKED, bool STREAM>
 __global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restrict__ in, PackBatch pb,
                                                              cplx *__restrict__ out, int64_t N, int64_t Ns)
 {
@@ -246,8 +249,18 @@ __global__ __launch_bounds__(256) void stockham_fused_kernel(const cplx *__restr
         const int64_t jo = jb + j2;
         const int64_t ko = jo & (Ns - 1);
         const int64_t obase = (jo - ko) * R + ko;
+        if constexpr (STREAM) {
+            // a buffer larger than the last-level cache: written past it
 #pragma unroll
-        for (int h = 0; h < 16; ++h) dst[obase + (int64_t)(u + A * h) * Ns] = z[h];
+            for (int h = 0; h < 16; ++h) {
+                cplx *o = dst + obase + (int64_t)(u + A * h) * Ns;
+                __builtin_nontemporal_store(z[h].x, &o->x);
+                __builtin_nontemporal_store(z[h].y, &o->y);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 16; ++h) dst[obase + (int64_t)(u + A * h) * Ns] = z[h];
+        }
     }
 }
 
@@ -297,21 +310,33 @@ cplx *fft_c2c(cplx *a, cplx *b, int64_t N, int batch, hipStream_t st, const Pack
         src = dst;
         dst = t;
     };
+    // 256 MiB of last-level cache: what is larger than half of it is written past it
+    const bool stream_out = (size_t)batch * (size_t)N * sizeof(cplx) > ((size_t)128 << 20);
     auto launch_fused = [&](int A, bool first) {
         const int R = A * 16;
         dim3 grid((unsigned)(N / R / 16), (unsigned)batch);
 #define FUSED(A_)                                                                                     \
     if (A == A_) {                                                                                    \
-        if (first)                                                                                    \
-            hipLaunchKernelGGL((stockham_fused_kernel<A_, true, false>), grid, dim3(256), 0, st,      \
+        if (first && stream_out)                                                                      \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, true, false, true>), grid, dim3(256), 0, st, \
+                               (const cplx *)src, nopack, dst, N, Ns);                                \
+        else if (first)                                                                               \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, true, false, false>), grid, dim3(256), 0, st, \
+                               (const cplx *)src, nopack, dst, N, Ns);                                \
+        else if (stream_out)                                                                          \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, false, false, true>), grid, dim3(256), 0, st, \
                                (const cplx *)src, nopack, dst, N, Ns);                                \
         else                                                                                          \
-            hipLaunchKernelGGL((stockham_fused_kernel<A_, false, false>), grid, dim3(256), 0, st,     \
+            hipLaunchKernelGGL((stockham_fused_kernel<A_, false, false, false>), grid, dim3(256), 0, st, \
                                (const cplx *)src, nopack, dst, N, Ns);                                \
     }
         if (first && packed_first) {
-            hipLaunchKernelGGL((stockham_fused_kernel<16, true, true>), grid, dim3(256), 0, st,
-                               (const cplx *)nullptr, *pack, dst, N, Ns);
+            if (stream_out)
+                hipLaunchKernelGGL((stockham_fused_kernel<16, true, true, true>), grid, dim3(256), 0, st,
+                                   (const cplx *)nullptr, *pack, dst, N, Ns);
+            else
+                hipLaunchKernelGGL((stockham_fused_kernel<16, true, true, false>), grid, dim3(256), 0, st,
+                                   (const cplx *)nullptr, *pack, dst, N, Ns);
         } else {
             FUSED(2) FUSED(4) FUSED(8) FUSED(16)
         }
