@@ -75,6 +75,7 @@ SIGNATURES = {
     'godot_select_cells_static': (c_int, [c_f64p, c_i64, c_f64, c_i64p, c_i64p, c_stream]),
     'godot_gather_f64': (c_int, [c_f64p, c_i64p, c_i64, c_f64p, c_stream]),
     'godot_gather_i64': (c_int, [c_i64p, c_i64p, c_i64, c_i64p, c_stream]),
+    'godot_gather_columns': (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_i64p, c_i64, c_stream]),
     'godot_rfft_workspace_bytes': (c_size, [c_i64]),
     'godot_rfft_f64': (c_int, [c_f64p, c_i64, c_i64, c_f64p, c_ws, c_size, c_stream]),
     'godot_power_spectrum_workspace_bytes': (c_size, [c_i64]),

@@ -1313,13 +1313,13 @@ class Data(object):
 
         if trim_zero_exposure:
             keep = ops.select_cells(exp, 0.0)
-            starts, stops = ops.gather(starts, keep), ops.gather(stops, keep)
-            exp, sexp, bexp = ops.gather(exp, keep), ops.gather(sexp, keep), ops.gather(bexp, keep)
-            dead = ops.gather(dead, keep)
-            lo, hi, counts = ops.gather(lo, keep), ops.gather(hi, keep), ops.gather(counts, keep)
+            cols = [starts, stops, exp, sexp, bexp, dead, lo, hi, counts]
             if use_barycenter:
-                label_starts, label_stops = ops.gather(label_starts, keep), ops.gather(label_stops, keep)
-                alt_starts, alt_stops = ops.gather(alt_starts, keep), ops.gather(alt_stops, keep)
+                cols += [label_starts, label_stops, alt_starts, alt_stops]
+            cols = ops.gather_columns([c.contiguous() for c in cols], keep)     # one launch for the table
+            starts, stops, exp, sexp, bexp, dead, lo, hi, counts = cols[:9]
+            if use_barycenter:
+                label_starts, label_stops, alt_starts, alt_stops = cols[9:]
 
         we, ti = self.we, self.ti
         if src_injector is not None:
@@ -1426,8 +1426,8 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
     if trim_zero_exposure:
         # a cell has exposure exactly when it has source exposure (sexp = S / E * exp, S > 0)
         keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch
-        g = lambda x: ops.gather(x.contiguous(), keep)
-        lo, hi, starts, stops, sexp, bexp, source = g(lo), g(hi), g(starts), g(stops), g(sexp), g(bexp), g(source)
+        lo, hi, starts, stops, sexp, bexp, source = ops.gather_columns(
+            [c.contiguous() for c in (lo, hi, starts, stops, sexp, bexp, source)], keep)
         ncl = torch.bincount(source, minlength=len(per)).cpu().numpy()
     cells = CellBatch(we, ti, lo.contiguous(), hi.contiguous(), starts, stops, sexp, bexp)
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))

@@ -146,6 +146,61 @@ __device__ __forceinline__ int64_t upper_bound(const double *a, int64_t n, doubl
     return lo;
 }
 
+// The same searches inside [lo, hi): for callers that know the answer lies there (the
+// threads of a workgroup whose queries are sorted: the answers of its first and last thread
+// bracket all the others, and 256 neighbouring cells span a few thousand elements, not 10^7:
+// half the probes, and all of them in a few tens of KB that stay in cache).
+__device__ __forceinline__ int64_t lower_bound_in(const double *a, int64_t lo, int64_t hi, double v)
+{
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int64_t upper_bound_in(const double *a, int64_t lo, int64_t hi, double v)
+{
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// lower_bound (UPPER = false) or upper_bound of a value that is the same in every lane,
+// found by the 64 lanes of a wavefront together: a step probes 64 evenly spaced elements,
+// one a lane, and keeps the 64th of the range the answer lies in -- four load latencies for
+// 10^7 elements where a lane on its own takes twenty-four.  All 64 lanes must be active.
+template <bool UPPER>
+__device__ __forceinline__ int64_t bound_by_wave(const double *a, int64_t n, double v)
+{
+    const int lane = threadIdx.x & 63;
+    // invariant: the predicate (a[i] < v, or a[i] <= v) holds for every i < lo and for no i >= hi
+    int64_t lo = 0, hi = n;
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) >> 6;
+        const int64_t p = lo + step * (lane + 1) - 1;
+        bool t = false;
+        if (p < hi) {
+            const double x = a[p];
+            t = UPPER ? x <= v : x < v;
+        }
+        const int cnt = __popcll(__ballot(t));              // the first cnt probes hold
+        const int64_t failed = lo + step * (cnt + 1) - 1;   // the first probe that does not, if in range
+        lo += step * cnt;
+        if (failed < hi) hi = failed;
+    }
+    const int64_t p = lo + lane;
+    bool t = false;
+    if (p < hi) {
+        const double x = a[p];
+        t = UPPER ? x <= v : x < v;
+    }
+    return lo + __popcll(__ballot(t));
+}
+
 struct ExposureLoad {
     const double *tstart, *tstop, *exposure, *livetime;
     double s_over_e, b_over_e;
@@ -711,13 +766,39 @@ inline size_t cs_scratch_bytes(int64_t n)
 }
 
 // cumulative exposures at the query times: core.py:1806-1832
-__global__ void exposure_query_kernel(ExposureLoad ld, const Quad *cum, int64_t n_ft2, const double *times,
-                                      int64_t n_t, Quad *at)
+__global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, const Quad *cum, int64_t n_ft2,
+                                                             const double *times, int64_t n_t, Quad *at)
 {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // sorted queries (cell edges): the rows of the workgroup's first and last query bracket
+    // the rows of all the others; those two are searched for by a wavefront each
+    __shared__ double s_t[2];
+    __shared__ int64_t s_i[2];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t kb = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t kl = (kb + blockDim.x < n_t ? kb + blockDim.x : n_t) - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        const double tb = times[kb];
+        const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tb);
+        if (lane == 0) {
+            s_t[0] = tb;
+            s_i[0] = r;
+        }
+    }
+    if (wave == (int)((kl - kb) >> 6)) {
+        const double tl = times[kl];
+        const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tl);
+        if (lane == 0) {
+            s_t[1] = tl;
+            s_i[1] = r;
+        }
+    }
+    __syncthreads();
     if (k >= n_t) return;
-    double t = times[k];
-    int64_t idx = lower_bound(ld.tstop, n_ft2, t);
+    const double t = times[k];
+    int64_t idx;
+    if (s_t[0] <= t && t <= s_t[1]) idx = lower_bound_in(ld.tstop, s_i[0], s_i[1], t);
+    else idx = lower_bound(ld.tstop, n_ft2, t);   // unsorted queries, NaN
     if (idx >= n_ft2) idx = n_ft2 - 1;   // the reference would index out of range here
     double t0 = ld.tstart[idx], t1 = ld.tstop[idx];
     double frac = __ddiv_rn(__dsub_rn(t, t0), __dsub_rn(t1, t0));
@@ -745,13 +826,40 @@ __global__ void exposure_out_kernel(const Quad *at, int64_t n_out, int cumulativ
 }
 
 // photon range of every cell (see godot_bin_photons in the header)
-__global__ void bin_photons_kernel(const double *ti, int64_t nph, double start0, const double *stops,
-                                   int64_t ncell, int64_t *lo, int64_t *hi, int64_t *counts)
+__global__ __launch_bounds__(256) void bin_photons_kernel(const double *ti, int64_t nph, double start0,
+                                                          const double *stops, int64_t ncell, int64_t *lo,
+                                                          int64_t *hi, int64_t *counts)
 {
-    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one search per cell: where its stop falls among the photon times; a cell starts where
+    // the cell before it ends, which the neighbouring thread has found.  The stops are
+    // sorted, so the workgroup's first and last answers bracket the rest.
+    __shared__ int64_t ends[257];
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cb = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t cl = (cb + blockDim.x < ncell ? cb + blockDim.x : ncell) - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {   // where the workgroup's first cell starts
+        const int64_t r = (cb == 0) ? bound_by_wave<false>(ti, nph, start0) : bound_by_wave<true>(ti, nph, stops[cb - 1]);
+        if (lane == 0) ends[0] = r;
+    }
+    if (wave == (int)((cl - cb) >> 6)) {   // where its last cell ends
+        const int64_t r = (cl == ncell - 1) ? bound_by_wave<false>(ti, nph, stops[cl]) : bound_by_wave<true>(ti, nph, stops[cl]);
+        if (lane == 0) ends[cl - cb + 1] = r;
+    }
+    __syncthreads();
+    if (c < cl) {
+        const double sc = stops[c];
+        // holds for sorted stops; a thread for which it does not searches the whole list
+        const bool bracketed = (cb == 0 || stops[cb - 1] <= sc) && sc < stops[cl];
+        const int64_t wlo = cb == 0 ? 0 : ends[0];   // the first cell's start may lie beyond its stop
+        const int64_t whi = ends[cl - cb + 1];
+        ends[threadIdx.x + 1] =
+            (bracketed && wlo <= whi) ? upper_bound_in(ti, wlo, whi, sc) : upper_bound(ti, nph, sc);
+    }
+    __syncthreads();
     if (c >= ncell) return;
-    int64_t l = (c == 0) ? lower_bound(ti, nph, start0) : upper_bound(ti, nph, stops[c - 1]);
-    int64_t h = (c == ncell - 1) ? lower_bound(ti, nph, stops[c]) : upper_bound(ti, nph, stops[c]);
+    const int64_t l = ends[threadIdx.x];
+    int64_t h = ends[threadIdx.x + 1];
     if (h < l) h = l;   // start0 beyond the first stop: empty first cell
     lo[c] = l;
     hi[c] = h;
@@ -780,6 +888,20 @@ __global__ void gather_kernel(const T *src, const int64_t *idx, int64_t n, T *ds
     if (k < n) dst[k] = src[idx[k]];
 }
 
+// The same selection applied to several per-cell arrays of 8-byte elements at once
+// (the columns of a cell table: starts, stops, exposures, photon ranges, ...).
+constexpr int GATHER_MAX_COLUMNS = 16;
+struct GatherColumns {
+    const uint64_t *src[GATHER_MAX_COLUMNS];
+    uint64_t *dst[GATHER_MAX_COLUMNS];
+};
+__global__ void gather_columns_kernel(GatherColumns c, int ncol, const int64_t *idx, int64_t n)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i = idx[k];
+    for (int a = 0; a < ncol; ++a) c.dst[a][k] = c.src[a][i];
+}
 
 // numpy.searchsorted(a, v, side): out[k] = first index with a[i] >= v[k] (left) or > v[k] (right)
 __global__ void search_sorted_kernel(const double *a, int64_t n, const double *v, int64_t nv, int right,
@@ -1160,6 +1282,27 @@ extern "C" int godot_gather_f64(const double *src, const int64_t *idx, int64_t n
     hipLaunchKernelGGL(gather_kernel<double>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, idx, n, dst);
     GODOT_LAUNCH_CHECK("godot_gather_f64");
+    return GODOT_OK;
+}
+
+extern "C" int godot_gather_columns(const void *const *src, void *const *dst, int ncol, const int64_t *idx,
+                                    int64_t n, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(n >= 0, GODOT_E_INVALID, "godot_gather_columns: negative n");
+    GODOT_REQUIRE(ncol >= 0 && ncol <= GATHER_MAX_COLUMNS, GODOT_E_UNSUPPORTED,
+                  "godot_gather_columns: at most 16 columns a call");
+    if (n == 0 || ncol == 0) return GODOT_OK;
+    GODOT_REQUIRE(src && dst && idx, GODOT_E_INVALID, "godot_gather_columns: null argument");
+    GatherColumns c{};
+    for (int a = 0; a < ncol; ++a) {
+        GODOT_REQUIRE(src[a] && dst[a], GODOT_E_INVALID, "godot_gather_columns: null column");
+        c.src[a] = (const uint64_t *)src[a];
+        c.dst[a] = (uint64_t *)dst[a];
+    }
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, c, ncol, idx, n);
+    GODOT_LAUNCH_CHECK("godot_gather_columns");
     return GODOT_OK;
 }
 

@@ -309,6 +309,12 @@ int godot_gather_f64(const double *src, const int64_t *idx, int64_t n,
                      double *dst, godot_stream_t stream);
 int godot_gather_i64(const int64_t *src, const int64_t *idx, int64_t n,
                      int64_t *dst, godot_stream_t stream);
+/* The trimming of every per-cell array by the one mask (core.py:2113-2122:
+ * starts[mask], stops[mask], exp[mask], ...) in one launch: dst[a][k] =
+ * src[a][idx[k]] for ncol <= 16 arrays of 8-byte elements (double or int64).
+ * src and dst are HOST arrays of ncol device pointers.                        */
+int godot_gather_columns(const void *const *src, void *const *dst, int ncol,
+                         const int64_t *idx, int64_t n, godot_stream_t stream);
 
 /* ---- power spectra: core.py:2598-2782 -------------------------------------- */
 

@@ -26,6 +26,9 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU S
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/grid_write -- python3 $R/profiles/grid_once.py > $OUT/grid_write.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grid_trace -- python3 $R/profiles/grid_once.py > $OUT/grid_trace.log 2>&1 || exit 1
 # 7. the plain bench line (no profiler attached)
+T0=$SECONDS
 timeout -k 10 600 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+WALL=$((SECONDS - T0))
 python3 $R/profiles/summarize_r2.py $OUT > $OUT/summary.txt
+echo "# wall time of the plain 'python3 bench.py' above: $WALL s" >> $OUT/summary.txt
 tail -5 $OUT/summary.txt

@@ -102,8 +102,8 @@ def main():
     ff = counters(root, 'fft_fetch', 'rocprofv3 --pmc FETCH_SIZE (KB): profiles/fft_once.py', '')
     fw = counters(root, 'fft_write', 'rocprofv3 --pmc WRITE_SIZE (KB): profiles/fft_once.py', '')
     if ff and fw:
-        fetch = sum(v['FETCH_SIZE'][0] * v['FETCH_SIZE'][1] for k, v in ff.items() if 'stockham' in k or 'epilogue' in k) / 3
-        write = sum(v['WRITE_SIZE'][0] * v['WRITE_SIZE'][1] for k, v in fw.items() if 'stockham' in k or 'epilogue' in k) / 3
+        fetch = sum(v['FETCH_SIZE'][0] * v['FETCH_SIZE'][1] for k, v in ff.items() if 'stockham' in k or k.startswith('ps_')) / 3
+        write = sum(v['WRITE_SIZE'][0] * v['WRITE_SIZE'][1] for k, v in fw.items() if 'stockham' in k or k.startswith('ps_')) / 3
         alg = 5 * (8 * 3786912 + 16 * ((1 << 25) // 4 + 1))
         print('# power_spectrum_fft, per call: FETCH_SIZE %.0f KB (x2 on gfx950), WRITE_SIZE %.0f KB -> traffic %.3f GB; '
               'algorithmic %.3f GB; ratio %.2f' % (fetch, write, (2 * fetch + write) * 1024 / 1e9, alg / 1e9,

@@ -192,3 +192,30 @@ def test_running_sums_are_numpy_cumsum_bit_for_bit(case):
         want = [np.cumsum(x1), np.cumsum(se * x1), np.cumsum(be * x1), np.cumsum((x4 - 0.0) - 0.0)]
     for c in range(4):
         assert _same_bits(got[:, c], want[c]), (case, c, int(np.argmax(got[:, c].view(np.int64) != want[c].view(np.int64))))
+
+
+def test_gather_columns_is_the_per_column_gather():
+    """The cell table trimmed in one launch: float64 and int64 columns, more columns than
+    one launch takes, an empty selection."""
+    import torch
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu')
+    g.manual_seed(5)
+    n = 100_003
+    cols = []
+    for a in range(19):
+        if a % 3 == 2:
+            cols.append(torch.randint(-2**62, 2**62, (n,), generator=g, dtype=torch.int64).to(dev))
+        else:
+            c = torch.randn(n, generator=g, dtype=torch.float64)
+            c[::977] = float('nan')                       # payload bits must survive
+            cols.append(c.to(dev))
+    idx = torch.sort(torch.randperm(n, generator=g)[:40_001])[0].to(dev)
+    out = ops.gather_columns(cols, idx)
+    assert len(out) == len(cols)
+    for c, o in zip(cols, out):
+        assert o.dtype == c.dtype
+        assert torch.equal(o.view(torch.int64), c[idx].view(torch.int64))
+    empty = ops.gather_columns(cols[:3], idx[:0])
+    assert all(e.numel() == 0 for e in empty)
