@@ -492,6 +492,11 @@ class CellLogLikelihood(object):
         return self.get_logpdf(aopt=aopt, dlogl=dlogl, npt=npt, include_zero=include_zero,
                                profile_background=True)
 
+    def fmin_fsolve_jac(self, p):
+        """Declared and left empty in the reference (core.py:476-477); kept for callers that
+        look the name up."""
+        return None
+
     def f1(self, alpha):
         return self._sums(alpha)[1] - self.S
 
