@@ -258,3 +258,42 @@ def test_spectrum_from_separately_transformed_series():
         sc = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 1e-9 * sc and np.abs(got - fused).max() <= 1e-9 * sc
     assert np.allclose(amps.cpu().numpy()[:, 1:], qamps.cpu().numpy()[:, 1:], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize('lg,frac', [(17, 0.9), (18, 0.113), (19, 1.0), (20, 0.5), (21, 0.113), (23, 0.05)])
+def test_spectrum_whose_last_pass_forms_the_estimators(lg, frac):
+    """Padded lengths from 2^17 on take the kernel that runs the last pass of all five
+    transforms, splits them into the real transforms' bins and evaluates the estimators
+    without writing a transform out: every bin (the first, the last at l/4, those of
+    columns 0 and S/2 that pair with themselves) against numpy's transforms, with the
+    amplitudes, for series that fill the padded length and series that leave most of it
+    empty."""
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(100 + lg)
+    l = 1 << lg
+    nbin = max(8, int(l * frac))
+    cnt = rng.poisson(3.0, nbin).astype(float)
+    W = cnt * rng.uniform(0.1, 0.3, nbin)
+    WW = W * rng.uniform(0.2, 0.6, nbin)
+    S = rng.uniform(0.5, 1.5, nbin) * W.mean()
+    B = rng.uniform(0.5, 1.5, nbin) * (cnt - W).mean()
+    Wb, WbWb = cnt - W, cnt - 2 * W + WW
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    q0, q1, qb, qamps = ops.power_spectrum_fft(d(W), d(WW), d(S), d(Wb), d(WbWb), d(B), l, want_amps=True)
+    nk = l // 4 + 1
+    f = [np.fft.rfft(x, n=l) for x in (W - S, Wb - B, WW, WbWb, W - WW)]
+    parts = (f[0][:nk], f[1][:nk], f[2][::2], f[3][::2], f[4][::2])
+    with np.errstate(all='ignore'):
+        r0, r1, rb = orc.power_spectrum_from_parts(*parts)
+        ramps = orc.power_spectrum_from_parts(*parts, get_amps=True)
+    assert q0.numel() == nk
+    for got, ref in ((q0, r0), (q1, r1), (qb, rb)):
+        got = got.cpu().numpy()
+        sc = np.abs(ref[1:]).max()
+        assert np.abs(got[1:] - ref[1:]).max() <= 1e-9 * sc
+        assert np.isnan(got[0]) == np.isnan(ref[0]) and (np.isnan(ref[0]) or abs(got[0] - ref[0]) <= 1e-9 * sc)
+    got = qamps.cpu().numpy()
+    ramps = np.asarray(ramps)
+    sc = np.abs(ramps[:, 1:]).max(axis=1, keepdims=True)
+    assert (np.abs(got[:, 1:] - ramps[:, 1:]) <= 1e-8 * sc).all()
