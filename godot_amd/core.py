@@ -1540,7 +1540,9 @@ def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False,
         l = W.numel()
     if l < W.numel():
         raise NotImplementedError('dfgoal gives a transform shorter than the series')
-    freqs = np.fft.rfftfreq(l)[:l // 4 + 1] / cells.tsamp()
+    # np.fft.rfftfreq(l) / tsamp cut to l // 4 + 1 bins (core.py:2679) without forming the other half of
+    # rfftfreq's array: the same products and quotients, element for element
+    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) / cells.tsamp()
     p0, p1, pb, amps = ops.power_spectrum_fft(W.contiguous(), WW.contiguous(), S.contiguous(),
                                               Wb.contiguous(), WbWb.contiguous(), B.contiguous(),
                                               l, want_amps=get_amps)
@@ -1558,7 +1560,7 @@ def power_spectrum_simple(timeseries, get_amps=False, device=None):
     W, WW, S = _ts_dev(ts, 'weights', dev), _ts_dev(ts, 'weights2', dev), _ts_dev(ts, 'sexp', dev)
     l = W.numel()
     dl, mom = ops.power_spectrum_simple(W, WW, S, want_moments=get_amps)
-    freqs = np.fft.rfftfreq(l)[:(l // 4 + 1)] * (1. / ts.tsamp())
+    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) * (1. / ts.tsamp())   # rfftfreq(l)[:l // 4 + 1], same products
     if get_amps:
         m = _np(mom)
         return freqs, _np(dl), (m[0], m[1], m[2], m[3])
