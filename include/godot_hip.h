@@ -181,7 +181,8 @@ int godot_cell_logpdf_profile(const double *we, int64_t nph,
  * differences of the sums (and therefore the zero-exposure trimming mask) are
  * bit-identical to the reference's (long tables are summed in parallel with
  * the sequential result's own roundings).  `table` (device,
- * godot_exposure_table_bytes bytes: the sums followed by scratch of the build)
+ * godot_exposure_table_bytes bytes: the sums, then the six numbers a query reads
+ * of its row side by side -- 80 bytes a row in all -- and scratch of the build)
  * depends only on the exposure table and the two scale factors: build it
  * once, reuse it for every godot_exposure_at call.                            */
 size_t godot_exposure_table_bytes(int64_t n_ft2);
