@@ -417,6 +417,42 @@ def run_rank(args):
         extra['strong_c4_z2m'] = zrec
         del zws, zt, zw, zbuf
         torch.cuda.empty_cache()
+        # (3) C3: ONE power spectrum (3 786 912 bins of 100 s, l = 2^25) with its five transforms
+        # dealt over the ranks; every step transforms the rank's series, all-gathers the five
+        # transforms cut to what the estimators read and forms the estimators on every rank.
+        # (On one GPU the whole call is a single fused pipeline: extra.power_spectrum_fft.)
+        nb3, l3 = 3_786_912, 1 << 25
+        gen3 = torch.Generator(device=dev)
+        gen3.manual_seed(13)                                   # the same series on every rank
+        cnt3 = torch.poisson(torch.full((nb3,), 2.6, dtype=torch.float64, device=dev), generator=gen3)
+        W3, WW3 = cnt3 * 0.17, cnt3 * 0.08
+        S3 = torch.full((nb3,), 0.44, dtype=torch.float64, device=dev)
+        B3 = S3 * 5
+        Wb3, WbWb3 = cnt3 - W3, cnt3 - 2 * W3 + WW3
+        series3 = [W3 - S3, Wb3 - B3, WW3, WbWb3, W3 - WW3]
+
+        def c3_step():
+            return gd.power_spectrum_fft_sharded(lambda i: series3[i], l3, ops.rfft,
+                                                 lambda *parts: ops.power_spectrum_from_parts(*parts))
+
+        for _ in range(2):
+            c3_step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            p3 = c3_step()
+        torch.cuda.synchronize()
+        barrier()
+        t_c3 = max_over_ranks(time.perf_counter() - t0) / 5
+        extra['strong_c3_fft'] = dict(ms=t_c3 * 1e3, nbins=nb3, l=l3, n_gpus=world,
+                                      transforms_on_rank0=len(gd.transform_shard(5, rank, world)),
+                                      gathered_MB=5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0,
+                                      p0_at_bin_1=float(p3[0][1]),
+                                      sharding='the five transforms dealt over the ranks (dist.transform_shard), '
+                                               'cut transforms all-gathered, estimators on every rank')
+        del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
+        torch.cuda.empty_cache()
 
     if rank != 0:
         if dist is not None:
@@ -559,7 +595,7 @@ def run_rank(args):
                                'alpha-hat + TS fit; %d lists per GPU fitted in rotation' % (
                                    args.nph, args.years, args.tcell, ncells[0], NLIST),
                    'parallelism': 'every GPU fits its own photon lists, no collective in the timed steps '
-                                  '(extra.strong_c2_fit and extra.strong_c4_z2m: one job split over the GPUs, '
+                                  '(extra.strong_c2_fit, extra.strong_c4_z2m, extra.strong_c3_fft: one job split over the GPUs, '
                                   'collectives timed)'},
         'roofline': roofline,
         'cpu_baseline': cpu,

@@ -273,17 +273,19 @@ def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None):
     if world > 1:
         slots = -(-5 // min(world, 5))
         ref = next(iter(parts.values())) if parts else None
-        dev = ref.device if ref is not None else _device_of(group)
+        cdev = _device_of(group)                       # where the collective runs (the host under gloo)
+        dev = ref.device if ref is not None else cdev  # where the estimators are formed
         dtype = ref.dtype if ref is not None else torch.float64
-        buf = torch.zeros((slots, nk, 2), dtype=dtype, device=dev)
+        buf = torch.zeros((slots, nk, 2), dtype=dtype, device=cdev)
         for s_, i in enumerate(mine):
-            buf[s_] = parts[i]
-        allbuf = torch.empty((world * slots, nk, 2), dtype=dtype, device=dev)
+            buf[s_] = parts[i].to(cdev)
+        allbuf = torch.empty((world * slots, nk, 2), dtype=dtype, device=cdev)
         dist.all_gather_into_tensor(allbuf, buf, group=group)
         allbuf = allbuf.view(world, slots, nk, 2)
         for r in range(min(world, 5)):
             for s_, i in enumerate(transform_shard(5, r, world)):
-                parts[i] = allbuf[r, s_]
+                if i not in parts:
+                    parts[i] = allbuf[r, s_].to(dev)
     return estimate_fn(parts[0], parts[1], parts[2], parts[3], parts[4])
 
 
