@@ -6,7 +6,7 @@ reference's get_max + get_ts) of every cell of one photon list of the workload
     C2: 1e7 synthetic photons, 10 yr, 10-minute cells (zero-exposure cells
         trimmed), cells built by the GPU binning path,
 with all inputs resident in HBM.  Every rank owns NLIST = 4 such lists (seeds
-11 + 4 rank + j) and the steps go round them, so that 376 MB of other inputs
+11 + 4 rank + j) and the steps go round them, so that 293 MB of other inputs
 pass between two fits of the same list: more than the 256 MiB Infinity Cache
 holds, the weights come from HBM.  Weak scaling: the path has no exchange
 between ranks, so the timed steps hold no collective; value = cells fitted per
@@ -16,11 +16,12 @@ second by all ranks.
 ranks itself (fresh child processes, before this process touches a GPU).
 
 Also reported (rank 0, "extra"):
-  * strong scaling of the two sharded jobs, collectives inside the timed
+  * strong scaling of three sharded jobs, collectives inside the timed
     region: C2's cells of ONE list split over the ranks by photon count, the
     per-cell records all-gathered every step; C4 (1e6 photons x 1e8 trial
     frequencies, m = 2) with the frequencies split over the ranks and the global
-    top ten gathered;
+    top ten gathered; one C3 power spectrum with its five transforms dealt over
+    the ranks and the cut transforms all-gathered;
   * the same fit on one list kept in the cache, the 200-point profile grid,
     dense cells, power_spectrum_fft at the C3 size, binning, Bayesian Blocks;
   * CPU baselines: the numpy oracle (a restatement of the reference's Python
