@@ -15,7 +15,7 @@
 // formed once per cell by a kernel of their own, with the same IEEE division,
 // so the interpolated values are the reference's to the last bit (this file
 // is compiled without FMA contraction: numpy multiplies, rounds, then adds).
-// The dynamic programme over the rows (core.py:1146-1161) goes in blocks of 1024 rows:
+// The dynamic programme over the rows (core.py:1146-1161) goes in blocks of 256 rows:
 // the candidates below a block on all CUs, those inside it in one workgroup, 64 rows
 // at a time (see bb_below_kernel / bb_within_kernel).
 
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_fitness_kernel(const double *__
 //                     wavefronts, those inside it by one wavefront row after
 //                     row without a barrier.
 constexpr int BP_K = 64;
-constexpr int BP_BLOCK = 1024;
+constexpr int BP_BLOCK = 256;
 constexpr int BP_NONE = 0x7fffffff;
 
 __global__ __launch_bounds__(256) void bb_below_kernel(const double *__restrict__ fit_val, int64_t i0, double prior,
@@ -295,11 +295,27 @@ __global__ __launch_bounds__(256) void bb_below_kernel(const double *__restrict_
 
 // value and first lane of the maximum over a wavefront, in numpy.argmax's order (a NaN
 // beats everything, ties go to the lower lane): one max-reduction and two ballots
+// maximum over the 64 lanes of values that hold no NaN, without a trip through LDS: four
+// DPP steps inside the rows of sixteen lanes, the four row maxima read as scalars
+__device__ __forceinline__ double wave_max_no_nan(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    auto row = [&](int l) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    };
+    return fmax(fmax(row(0), row(16)), fmax(row(32), row(48)));
+}
+
 __device__ __forceinline__ Best wave_best_by_lane(double v, int base)
 {
     const unsigned long long nan_lanes = __ballot(isnan(v) ? 1 : 0);
     if (nan_lanes) return Best{qnan(), base + (int)__builtin_ctzll(nan_lanes)};
-    const double m = team_max<64>(v);
+    const double m = wave_max_no_nan(v);
     const unsigned long long at = __ballot(v == m ? 1 : 0);
     return Best{m, base + (int)__builtin_ctzll(at)};
 }
@@ -310,48 +326,77 @@ __global__ __launch_bounds__(1024) void bb_within_kernel(const double *__restric
 {
     __shared__ double s_v[BP_K];
     __shared__ int s_k[BP_K];
-    __shared__ double s_best[BP_K + 1];       // best[i0 .. i0 + 64] of the stretch
+    // (fit_val - prior) of the candidates inside the stretch: row t, candidates i0 .. i0 + t.
+    // Fetched by all wavefronts before the row-after-row part, which then waits for no memory.
+    __shared__ double s_tri[BP_K][BP_K + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (b0 == 0 && tid == 0) best[0] = 0.0;
     __syncthreads();
     for (int64_t i0 = b0; i0 < b1; i0 += BP_K) {
         const int kmax = (int)((b1 - i0) < BP_K ? (b1 - i0) : BP_K);
         // candidates of this block below the stretch, on top of what bb_below_kernel parked
-        for (int t = wave; t < kmax; t += 16) {
-            const int64_t i = i0 + t;
-            const double *row = fit_val + i * (i + 1) / 2;
-            Best b{-INFINITY, BP_NONE};
-            for (int64_t r = b0 + lane; r < i0; r += 64) b = best_of(b, Best{(row[r] - prior) + best[r], (int)r});
+        // (a wavefront takes rows wave, wave + 16, wave + 32, wave + 48 together: their loads do
+        // not depend on one another, and best[r] is read once for the four)
+        {
+            const double *rows[4];
+            Best bs[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
-                b = best_of(b, other);
+            for (int u = 0; u < 4; ++u) {
+                const int t = wave + 16 * u;
+                const int64_t i = i0 + (t < kmax ? t : 0);
+                rows[u] = fit_val + i * (i + 1) / 2;
+                bs[u] = Best{-INFINITY, BP_NONE};
+                if (t < kmax) s_tri[t][lane] = lane <= t ? rows[u][i0 + lane] - prior : -INFINITY;
             }
-            if (lane == 0) {
-                if (b0 > 0) b = best_of(Best{best[i + 1], (int)last[i]}, b);
-                s_v[t] = b.v;
-                s_k[t] = b.k;
+            for (int64_t r = b0 + lane; r < i0; r += 64) {
+                const double br = best[r];
+                double fv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fv[u] = rows[u][r];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bs[u] = best_of(bs[u], Best{(fv[u] - prior) + br, (int)r});
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = wave + 16 * u;
+                Best b = bs[u];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    Best other{__shfl_xor(b.v, o, WAVE), __shfl_xor(b.k, o, WAVE)};
+                    b = best_of(b, other);
+                }
+                if (lane == 0 && t < kmax) {
+                    const int64_t i = i0 + t;
+                    if (b0 > 0) b = best_of(Best{best[i + 1], (int)last[i]}, b);
+                    s_v[t] = b.v;
+                    s_k[t] = b.k;
+                }
             }
         }
-        if (tid == 0) s_best[0] = best[i0];
         __syncthreads();
-        // candidates inside the stretch: one wavefront, row after row
+        // candidates inside the stretch: one wavefront, row after row.  Lane l holds best[i0 + l]
+        // once row l - 1 has produced it; everything else a row needs was fetched above.
         if (wave == 0) {
+            double mine = lane == 0 ? best[i0] : 0.0;     // best[i0 + lane], when known
+            double tri = s_tri[0][lane], sv = s_v[0];
+            int sk = s_k[0];
             for (int t = 0; t < kmax; ++t) {
                 const int64_t i = i0 + t;
-                const double *row = fit_val + i * (i + 1) / 2;
-                double v = -INFINITY;
-                if (lane <= t) v = (row[i0 + lane] - prior) + s_best[lane];
+                const double v = lane <= t ? tri + mine : -INFINITY;
+                const Best below{sv, sk};
+                if (t + 1 < kmax) {                       // the next row's, while this one is reduced
+                    tri = s_tri[t + 1][lane];
+                    sv = s_v[t + 1];
+                    sk = s_k[t + 1];
+                }
                 // lanes are in the order of r: the first lane of the maximum is its first r
-                Best b = best_of(Best{s_v[t], s_k[t]}, wave_best_by_lane(v, (int)i0));
+                Best b = best_of(below, wave_best_by_lane(v, (int)i0));
                 if (b.k == BP_NONE) b.k = 0;
+                if (lane == t + 1) mine = b.v;
                 if (lane == 0) {
-                    s_best[t + 1] = b.v;
                     best[i + 1] = b.v;
                     last[i] = b.k;
                 }
-                // the wavefront's own LDS accesses stay in program order
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
         __syncthreads();
