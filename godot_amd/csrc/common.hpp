@@ -61,7 +61,10 @@ __device__ __forceinline__ int dpp_i32(int v)
 // Each step pairs two disjoint sub-groups whose lanes already agree, and
 // + / max / * are commutative, so every lane of the group ends with the
 // bit-identical result: branches taken on it are uniform across the group.
-#define GODOT_TEAM_REDUCE(NAME, TYPE, MOVE, SHFL, OP)                    \
+// Beyond sixteen lanes the rows' results (every lane of a row holds its row's by then) are
+// read as scalars and combined in the butterfly's own order, (r0 op r1) op (r2 op r3): the
+// same bits as exchanging them through the LDS crossbar (ds_bpermute), without its latency.
+#define GODOT_TEAM_REDUCE(NAME, TYPE, MOVE, LANE, OP)                    \
     template <int T>                                                     \
     __device__ __forceinline__ TYPE NAME(TYPE v)                         \
     {                                                                    \
@@ -69,21 +72,32 @@ __device__ __forceinline__ int dpp_i32(int v)
         if (T >= 4) { TYPE u = MOVE<0x4E>(v); v = OP(v, u); }            \
         if (T >= 8) { TYPE u = MOVE<0x141>(v); v = OP(v, u); }           \
         if (T >= 16) { TYPE u = MOVE<0x140>(v); v = OP(v, u); }          \
-        if (T >= 32) { TYPE u = SHFL(v, 16, WAVE); v = OP(v, u); }       \
-        if (T >= 64) { TYPE u = SHFL(v, 32, WAVE); v = OP(v, u); }       \
+        if (T >= 32) {                                                   \
+            const TYPE r0 = LANE(v, 0), r1 = LANE(v, 16), r2 = LANE(v, 32), r3 = LANE(v, 48); \
+            const TYPE a = OP(r0, r1), b = OP(r2, r3);                   \
+            if (T >= 64) v = OP(a, b);                                   \
+            else v = (threadIdx.x & 32) ? b : a;                         \
+        }                                                                \
         return v;                                                        \
     }
+__device__ __forceinline__ double lane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 #define GODOT_OP_ADD(a, b) ((a) + (b))
 #define GODOT_OP_MUL(a, b) ((a) * (b))
 #define GODOT_OP_MAX(a, b) (((b) > (a)) ? (b) : (a))
-GODOT_TEAM_REDUCE(team_sum, double, dpp_f64, __shfl_xor, GODOT_OP_ADD)
-GODOT_TEAM_REDUCE(team_prod, double, dpp_f64, __shfl_xor, GODOT_OP_MUL)
-GODOT_TEAM_REDUCE(team_max, double, dpp_f64, __shfl_xor, GODOT_OP_MAX)
-GODOT_TEAM_REDUCE(team_sum_i32, int, dpp_i32, __shfl_xor, GODOT_OP_ADD)
+GODOT_TEAM_REDUCE(team_sum, double, dpp_f64, lane_f64, GODOT_OP_ADD)
+GODOT_TEAM_REDUCE(team_prod, double, dpp_f64, lane_f64, GODOT_OP_MUL)
+GODOT_TEAM_REDUCE(team_max, double, dpp_f64, lane_f64, GODOT_OP_MAX)
+GODOT_TEAM_REDUCE(team_sum_i32, int, dpp_i32, lane_i32, GODOT_OP_ADD)
 #define GODOT_OP_FMAX(a, b) fmax((a), (b))
 #define GODOT_OP_IMIN(a, b) (((b) < (a)) ? (b) : (a))
-GODOT_TEAM_REDUCE(team_fmax, double, dpp_f64, __shfl_xor, GODOT_OP_FMAX)    // ignores NaN
-GODOT_TEAM_REDUCE(team_min_i32, int, dpp_i32, __shfl_xor, GODOT_OP_IMIN)
+GODOT_TEAM_REDUCE(team_fmax, double, dpp_f64, lane_f64, GODOT_OP_FMAX)    // ignores NaN
+GODOT_TEAM_REDUCE(team_min_i32, int, dpp_i32, lane_i32, GODOT_OP_IMIN)
 
 // 1/d for finite d away from 0 and from the ends of the exponent range:
 // hardware estimate + two Newton steps (about 1 ulp).  No scaling, no
