@@ -722,32 +722,39 @@ __global__ __launch_bounds__(BK_THREADS) void cell_logpdf_spread_kernel(CellArgs
                 pr[u] = 1.0;
                 ex[u] = 0;
             }
+            // The photons stream in 16 bytes a lane, four loads of a thread in flight (a compute
+            // unit holds one such workgroup: twice the bytes on their way to it that 8-byte
+            // loads give; 3.3 10^6-photon cells: 1.99 -> 1.73 ms for the whole kernel, most of
+            // which is the search for the support with its exchanges between the workgroups).
+            const int head = (int)(((uintptr_t)w >> 3) & 1);    // w[0] on an odd 8-byte slot
+            const int64_t m = n > head ? n - head : 0;          // photons from the 16-byte boundary on
+            const double2 *wv = reinterpret_cast<const double2 *>(w + head);
+            const int64_t n2 = m >> 1;
+            auto fac = [&](int u, double x) { return fma(sg[u], x, of[u]); };
+            if (tid == 0 && head && n > 0) {
+#pragma unroll
+                for (int u = 0; u < BK_PPL; ++u) pr[u] *= fac(u, w[0]);
+            }
+            if (tid == 1 && (m & 1)) {
+#pragma unroll
+                for (int u = 0; u < BK_PPL; ++u) pr[u] *= fac(u, w[n - 1]);
+            }
             int64_t i = tid;
-            int k = 0;
-            for (; i + 3 * BK_THREADS < n; i += 4 * BK_THREADS) {
-                const double w0 = w[i], w1 = w[i + BK_THREADS], w2 = w[i + 2 * BK_THREADS],
-                             w3 = w[i + 3 * BK_THREADS];
+            for (; i + 3 * BK_THREADS < n2; i += 4 * BK_THREADS) {
+                const double2 a = wv[i], b = wv[i + BK_THREADS], c = wv[i + 2 * BK_THREADS],
+                              d = wv[i + 3 * BK_THREADS];
 #pragma unroll
-                for (int u = 0; u < BK_PPL; ++u)
-                    pr[u] *= (fma(sg[u], w0, of[u]) * fma(sg[u], w1, of[u])) *
-                             (fma(sg[u], w2, of[u]) * fma(sg[u], w3, of[u]));
-                if ((++k & 1) == 0) {
-#pragma unroll
-                    for (int u = 0; u < BK_PPL; ++u) {
-                        ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
-                        pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
-                    }
+                for (int u = 0; u < BK_PPL; ++u) {
+                    pr[u] *= ((fac(u, a.x) * fac(u, a.y)) * (fac(u, b.x) * fac(u, b.y))) *
+                             ((fac(u, c.x) * fac(u, c.y)) * (fac(u, d.x) * fac(u, d.y)));
+                    ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+                    pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
                 }
             }
+            for (; i < n2; i += BK_THREADS) {     // at most three pairs per thread
+                const double2 a = wv[i];
 #pragma unroll
-            for (int u = 0; u < BK_PPL; ++u) {
-                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
-                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
-            }
-            for (; i < n; i += BK_THREADS) {     // at most three photons per thread
-                const double wi = w[i];
-#pragma unroll
-                for (int u = 0; u < BK_PPL; ++u) pr[u] *= fma(sg[u], wi, of[u]);
+                for (int u = 0; u < BK_PPL; ++u) pr[u] *= fac(u, a.x) * fac(u, a.y);
             }
 #pragma unroll
             for (int u = 0; u < BK_PPL; ++u) {
