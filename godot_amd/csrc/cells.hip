@@ -803,7 +803,7 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     int gl, gr;
-    if (godot_detail::block_cells(nph, ncell)) {
+    if (godot_detail::fit_block_cells(nph, ncell)) {
         godot_detail::fit_block_launch(we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap, alpha, ts,
                                        flags, st);
     } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {

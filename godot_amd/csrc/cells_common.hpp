@@ -14,6 +14,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
 // very large cells, one workgroup each (cells_block.hip)
 bool block_cells(int64_t nph, int64_t ncell);
 bool logpdf_block_cells(int64_t nph, int64_t ncell);
+bool fit_block_cells(int64_t nph, int64_t ncell);
 void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
                       const double *B, int64_t ncell, const double *guess, double guess0, const double *beta,
                       double beta0, int swap, double *alpha, double *ts, int32_t *flags, hipStream_t st);

@@ -416,20 +416,25 @@ def test_zero_alpha_is_flagged_however_it_was_reached():
     assert (alpha == 0).sum() > 300 and clamped > 10
 
 
-@pytest.mark.parametrize('shape', ['spread64', 'one_workgroup'])
+@pytest.mark.parametrize('shape', ['spread64', 'one_workgroup', 'moderate_few'])
 def test_very_large_cells_by_layout(shape):
-    """The two layouts of very large cells: few cells, each spread over many workgroups
-    that exchange partial sums (3 cells of ~600 000 photons), and more cells than half the
-    compute units, one workgroup each (150 cells of ~17 000)."""
+    """The layouts of very large cells: few cells, each spread over many workgroups
+    that exchange partial sums (3 cells of ~600 000 photons); more cells than half the
+    compute units, one workgroup each (150 cells of ~17 000); and a few hundred cells of
+    5 000 to 9 000 photons (three-day cells of a bright source), which also get a
+    workgroup each because one wavefront per cell would stream them too slowly."""
     from godot_amd import ops
     dev = _dev()
     rng = np.random.default_rng(5 + len(shape))
     if shape == 'spread64':
         cnt = np.array([600001, 580000, 655003], dtype=np.int64)
         check = [0, 1, 2]
-    else:
+    elif shape == 'one_workgroup':
         cnt = rng.integers(16500, 18000, 150).astype(np.int64)
         check = [0, 7, 77, 149]
+    else:
+        cnt = rng.integers(5200, 9000, 300).astype(np.int64)
+        check = [0, 13, 150, 299]
     off = np.append(0, np.cumsum(cnt)).astype(np.int64)
     we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
     S = cnt * 0.17 * rng.choice([0.4, 1.0, 2.5], len(cnt))
