@@ -295,7 +295,10 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
 {
     constexpr int CW = 64 / L;                 // cells per wavefront
     constexpr int SLOTS = L * R;
-    constexpr int BOUNCE = 52 * R;             // photons in the wavefront's LDS slice
+    // photons in the wavefront's LDS slice: the run of its 64 / L cells.  Two lanes a cell:
+    // 32 cells of at most R + R - 3 sigma photons on average; four lanes: 16 cells whose
+    // mean may come to within two sigma of the 4 R slots, so that the run needs more room.
+    constexpr int BOUNCE = (L >= 4 ? 64 : 52) * R;
     constexpr int NLOAD = (BOUNCE + 63) / 64;
     constexpr int NWIDE = (BOUNCE + 127) / 128;   // rows of 128 photons: 16 bytes a lane
     using GC = GroupCell<L, R>;
@@ -942,6 +945,21 @@ bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R)
     else if (wide <= 41.0) { L = 2; R = 20; }
     else if (need <= 49.0) { L = 4; R = 12; }
     else if (need <= 66.0) { L = 4; R = 16; }
+    else if (need <= 82.0) { L = 4; R = 20; }
+    else if (need <= 98.0) { L = 4; R = 24; }
+    else if (need <= 114.0) { L = 4; R = 28; }
+    else if (need <= 130.0) { L = 4; R = 32; }
+    else if (need <= 162.0) { L = 8; R = 20; }
+    else if (need <= 194.0) { L = 8; R = 24; }
+    else if (need <= 258.0) { L = 16; R = 16; }
+    else if (need <= 322.0) { L = 16; R = 20; }
+    else if (need <= 386.0) { L = 16; R = 24; }
+    else if (need <= 514.0) { L = 32; R = 16; }
+    else if (need <= 642.0) { L = 32; R = 20; }
+    else if (need <= 770.0) { L = 32; R = 24; }
+    else if (need <= 1026.0) { L = 64; R = 16; }
+    else if (need <= 1282.0) { L = 64; R = 20; }
+    else if (need <= 1538.0) { L = 64; R = 24; }
     else return false;
     return true;
 }
@@ -990,6 +1008,21 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     GK_LAUNCH_INPLACE(2, 20)
     GK_LAUNCH_INPLACE(4, 12)
     GK_LAUNCH_INPLACE(4, 16)
+    GK_LAUNCH_INPLACE(4, 20)
+    GK_LAUNCH_INPLACE(4, 24)
+    GK_LAUNCH_INPLACE(4, 28)
+    GK_LAUNCH_INPLACE(4, 32)
+    GK_LAUNCH_INPLACE(8, 20)
+    GK_LAUNCH_INPLACE(8, 24)
+    GK_LAUNCH_INPLACE(16, 16)
+    GK_LAUNCH_INPLACE(16, 20)
+    GK_LAUNCH_INPLACE(16, 24)
+    GK_LAUNCH_INPLACE(32, 16)
+    GK_LAUNCH_INPLACE(32, 20)
+    GK_LAUNCH_INPLACE(32, 24)
+    GK_LAUNCH_INPLACE(64, 16)
+    GK_LAUNCH_INPLACE(64, 20)
+    GK_LAUNCH_INPLACE(64, 24)
 #undef GK_LAUNCH_INPLACE
 #undef GK_LAUNCH_TWO
 }
@@ -1012,6 +1045,21 @@ void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int6
     GP_LAUNCH(2, 20)
     GP_LAUNCH(4, 12)
     GP_LAUNCH(4, 16)
+    GP_LAUNCH(4, 20)
+    GP_LAUNCH(4, 24)
+    GP_LAUNCH(4, 28)
+    GP_LAUNCH(4, 32)
+    GP_LAUNCH(8, 20)
+    GP_LAUNCH(8, 24)
+    GP_LAUNCH(16, 16)
+    GP_LAUNCH(16, 20)
+    GP_LAUNCH(16, 24)
+    GP_LAUNCH(32, 16)
+    GP_LAUNCH(32, 20)
+    GP_LAUNCH(32, 24)
+    GP_LAUNCH(64, 16)
+    GP_LAUNCH(64, 20)
+    GP_LAUNCH(64, 24)
 #undef GP_LAUNCH
 }
 
