@@ -806,8 +806,8 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     if (godot_detail::fit_block_cells(nph, ncell)) {
         godot_detail::fit_block_launch(we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap, alpha, ts,
                                        flags, st);
-    } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
-        // sparse cells: groups of one to four lanes per cell (cells_group.hip)
+    } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr, false)) {
+        // groups of 1 to 64 lanes per cell (cells_group.hip)
         godot_detail::fit_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap,
                                        alpha, ts, flags, st);
     } else if (!beta && beta0 == 1.0) {
@@ -901,12 +901,18 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     GODOT_REQUIRE(B || !swap, GODOT_E_INVALID, "godot_cell_logpdf: swap needs B");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
-    int gl, gr;
-    if (godot_detail::logpdf_block_cells(nph, ncell)) {
+    int gl = 0, gr = 0;
+    const bool group = !godot_detail::block_cells(nph, ncell) && godot_detail::fit_group_shape(nph, ncell, gl, gr, true);
+    // lane groups (cells_group.hip) wherever a shape holds the cells and there are wavefronts
+    // enough to give every SIMD two; a workgroup per cell for very large cells and for few
+    // moderately large ones
+    if (group && ncell * gl >= 64 * 2048) {
+        godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
+                                          swap, dom, cod, flags, st);
+    } else if (godot_detail::logpdf_block_cells(nph, ncell)) {
         godot_detail::logpdf_block_launch(we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero, swap, dom,
                                           cod, flags, st);
-    } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr)) {
-        // sparse cells: groups of one to four lanes per cell (cells_group.hip)
+    } else if (group) {
         godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
                                           swap, dom, cod, flags, st);
     } else {

@@ -6,7 +6,7 @@
 
 // sparse-cell fit kernel (cells_group.hip), launched from godot_cell_fit
 namespace godot_detail {
-bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R);
+bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid);
 void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                       const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
                       const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,

@@ -298,7 +298,9 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     // photons in the wavefront's LDS slice: the run of its 64 / L cells.  Two lanes a cell:
     // 32 cells of at most R + R - 3 sigma photons on average; four lanes: 16 cells whose
     // mean may come to within two sigma of the 4 R slots, so that the run needs more room.
-    constexpr int BOUNCE = (L >= 4 ? 64 : 52) * R;
+    // (the largest shape also takes cells half again as long as its 2 048 slots: what does not
+    // fit the registers is read from the slice in every pass)
+    constexpr int BOUNCE = (L == 64 && R == 32 ? 96 : L >= 4 ? 64 : 52) * R;
     constexpr int NLOAD = (BOUNCE + 63) / 64;
     constexpr int NWIDE = (BOUNCE + 127) / 128;   // rows of 128 photons: 16 bytes a lane
     using GC = GroupCell<L, R>;
@@ -925,16 +927,22 @@ __global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, co
 
 namespace godot_detail {
 
-// Group shape for a mean occupancy.  The one-lane shapes and the first two-lane
-// shape hold the mean plus two (Poisson) sigma in their L*R register slots.
-// From there on the cells of a light curve are what decides: their sizes spread
-// wider than Poisson (the exposure of a cell varies along the orbit; ten-minute
-// cells of 22.6 photons on average have a standard deviation of 7, not 4.8), and
-// every photon beyond the slots costs a trip through the tail loops in all five
-// passes, so the two-lane shapes are chosen to hold the mean plus three sigma
-// (C2: 2 x 20 slots, 41.7 us against 49.3 us with 2 x 16).
-// Returns false when the cells are too dense for this kernel.
-bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R)
+// Shape of the lane groups (L lanes a cell, R register slots a lane) for a mean
+// occupancy.  The one-lane shapes and the first two-lane shape hold the mean plus two
+// (Poisson) sigma in their L*R slots.  From there on the cells of a light curve are what
+// decides: their sizes spread wider than Poisson (the exposure of a cell varies along the
+// orbit; ten-minute cells of 22.6 photons on average have a standard deviation of 7, not
+// 4.8), and every photon beyond the slots costs a trip through the tail loops in all five
+// passes, so the two-lane shapes are chosen to hold the mean plus three sigma (C2: 2 x 20
+// slots, 41.7 us against 49.3 us with 2 x 16).  Larger cells take 4 to 64 lanes: measured
+// on 10^7 photons these shapes fit cells of 40 to 1 400 photons in 35-45 us and form their
+// profile grids in 0.32-0.52 ms, where the team-per-cell kernels of cells.hip take 40-66 us
+// and 0.48-0.72 ms.  The largest shape keeps 3 072 photons in its LDS slice and reads what
+// its 2 048 slots do not hold from there (daily cells of 2 738 photons: fit 94 -> 47 us,
+// grid 0.70 -> 0.42 ms); for the fit alone the 64 x 32 team kernel is the faster up to its
+// own 2 048 slots (grid = false leaves those cells to it).
+// Returns false when no shape holds the cells.
+bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid)
 {
     const double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
     const double need = mean + 2.0 * sqrt(mean), wide = mean + 3.0 * sqrt(mean);
@@ -960,6 +968,7 @@ bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R)
     else if (need <= 1026.0) { L = 64; R = 16; }
     else if (need <= 1282.0) { L = 64; R = 20; }
     else if (need <= 1538.0) { L = 64; R = 24; }
+    else if (need <= 3000.0 && (grid || need > 2050.0)) { L = 64; R = 32; }
     else return false;
     return true;
 }
@@ -1023,6 +1032,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     GK_LAUNCH_INPLACE(64, 16)
     GK_LAUNCH_INPLACE(64, 20)
     GK_LAUNCH_INPLACE(64, 24)
+    GK_LAUNCH_INPLACE(64, 32)
 #undef GK_LAUNCH_INPLACE
 #undef GK_LAUNCH_TWO
 }
@@ -1060,6 +1070,7 @@ void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int6
     GP_LAUNCH(64, 16)
     GP_LAUNCH(64, 20)
     GP_LAUNCH(64, 24)
+    GP_LAUNCH(64, 32)
 #undef GP_LAUNCH
 }
 

@@ -215,7 +215,9 @@ def test_fit_matches_oracle_on_random_cells(nph, ncell):
     (105, 'scattered'), (135, 'plain'), (135, 'outliers'), (165, 'plain'), (165, 'guess'), (220, 'plain'),
     (220, 'beta'), (280, 'plain'), (280, 'swap'), (340, 'plain'), (450, 'plain'), (450, 'guess'), (580, 'plain'),
     (700, 'plain'), (700, 'beta'), (900, 'plain'), (900, 'scattered'), (1150, 'plain'), (1400, 'plain'),
-    (1400, 'guess')])
+    (1400, 'guess'),
+    # the largest shape: cells inside its 2 048 slots (the fit leaves those to the team kernel) and beyond them
+    (1700, 'plain'), (2300, 'plain'), (2300, 'beta'), (2700, 'plain'), (2700, 'guess'), (2700, 'swap')])
 def test_fit_sparse_cell_kernels(mean, variant):
     """Every shape of the lane-group kernel (1 to 64 lanes per cell; restarts
     in place or by the second kernel), with per-cell guesses, a background
@@ -284,7 +286,9 @@ def test_fit_sparse_cell_kernels(mean, variant):
                                           (62, 'plain'), (75, 'plain'), (90, 'swap'), (105, 'plain'),
                                           (135, 'given'), (165, 'plain'), (220, 'plain'), (280, 'outliers'),
                                           (340, 'plain'), (450, 'plain'), (580, 'given'), (700, 'plain'),
-                                          (900, 'plain'), (1150, 'swap'), (1400, 'plain'), (1400, 'npt300')])
+                                          (900, 'plain'), (1150, 'swap'), (1400, 'plain'), (1400, 'npt300'),
+                                          (1700, 'plain'), (2300, 'plain'), (2700, 'plain'), (2700, 'given'),
+                                          (2700, 'swap')])
 def test_logpdf_sparse_cell_kernels(mean, variant):
     """Profile grids of the sparse-cell kernel in every shape against the
     oracle's get_logpdf: centre found by the kernel or given, complemented
