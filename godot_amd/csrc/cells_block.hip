@@ -928,11 +928,12 @@ bool block_cells(int64_t nph, int64_t ncell)
 // Fits take a workgroup per cell also where the cells are well beyond the registers of a
 // 64-lane team (2 048 photons) and few: the dense-cell kernel then streams each cell with one
 // wavefront, a chain of loads as long as the cell, and a few thousand wavefronts leave most
-// SIMDs with a single one.  10^7 photons: 4 107 per cell 0.128 ms dense, 0.168 ms by
-// workgroups; 5 476: 0.161 and 0.135; 9 588: 0.263 and 0.102; 13 699: 0.359 and 0.076.
+// SIMDs with a single one.  10^7 photons: 4 107 per cell 0.084 ms dense, 0.168 ms by
+// workgroups; 5 476: 0.096 and 0.129; 6 496: 0.101 dense; 6 971: 0.112 by workgroups;
+// 9 588: 0.102 by workgroups (dense about 0.17); 13 699: 0.076 (dense about 0.24).
 bool fit_block_cells(int64_t nph, int64_t ncell)
 {
-    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)nph >= 5000.0 * (double)ncell);
+    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)nph >= 6500.0 * (double)ncell);
 }
 
 // Profile grids take a workgroup per cell also where the cells are only moderately large but

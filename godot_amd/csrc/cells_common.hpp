@@ -103,7 +103,16 @@ struct CellData {
             for (int r = 0; r < R; ++r)
                 if (ZS || has(r)) f(w[r], acc);
         } else {
-            for (int64_t i = lane; i < n; i += T) f(ld(i), acc);
+            // streamed cells: four loads of a lane in flight
+            int64_t i = lane;
+            for (; i + 3 * T < n; i += 4 * T) {
+                const double w0 = ld(i), w1 = ld(i + T), w2 = ld(i + 2 * T), w3 = ld(i + 3 * T);
+                f(w0, acc);
+                f(w1, acc);
+                f(w2, acc);
+                f(w3, acc);
+            }
+            for (; i < n; i += T) f(ld(i), acc);
         }
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<T>(acc[k]);
@@ -137,7 +146,19 @@ struct CellData {
                 }
             }
         } else {
-            for (int64_t i = lane; i < n; i += T) {
+            // streamed cells: four loads of a lane in flight, their reciprocals from one rcp
+            int64_t i = lane;
+            for (; i + 3 * T < n; i += 4 * T) {
+                const double w0 = ld(i), w1 = ld(i + T), w2 = ld(i + 2 * T), w3 = ld(i + 3 * T);
+                const double d0 = den(w0), d1 = den(w1), d2 = den(w2), d3 = den(w3);
+                double x0, x1, x2, x3;
+                rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+                accf(w0, d0, x0, acc);
+                accf(w1, d1, x1, acc);
+                accf(w2, d2, x2, acc);
+                accf(w3, d3, x3, acc);
+            }
+            for (; i < n; i += T) {
                 const double wv = ld(i), d = den(wv);
                 accf(wv, d, rcp_fast1(d), acc);
             }
@@ -229,11 +250,23 @@ struct CellData {
                 if ((r & 7) == 7) renorm();
             }
         } else {
-            for (int64_t i = lane; i < n; i += T) {
+            int64_t i = lane;
+            for (; i + 3 * T < n; i += 4 * T) {
+                const double w0 = ld(i), w1 = ld(i + T), w2 = ld(i + 2 * T), w3 = ld(i + 3 * T);
+                const double d0 = den(w0), d1 = den(w1), d2 = den(w2), d3 = den(w3);
+                double x0, x1, x2, x3;
+                rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+                gs += gf(w0, x0);
+                gs += gf(w1, x1);
+                gs += gf(w2, x2);
+                gs += gf(w3, x3);
+                pr *= (d0 * d1) * (d2 * d3);
+                if ((++k & 1) == 0) renorm();
+            }
+            for (; i < n; i += T) {
                 const double wv = ld(i), d = den(wv);
                 gs += gf(wv, rcp_fast1(d));
                 pr *= d;
-                if ((++k & 7) == 0) renorm();
             }
         }
         renorm();

@@ -437,13 +437,15 @@ def test_zero_alpha_is_flagged_however_it_was_reached():
     assert (alpha == 0).sum() > 300 and clamped > 10
 
 
-@pytest.mark.parametrize('shape', ['spread64', 'one_workgroup', 'moderate_few'])
+@pytest.mark.parametrize('shape', ['spread64', 'one_workgroup', 'moderate_few', 'streamed'])
 def test_very_large_cells_by_layout(shape):
     """The layouts of very large cells: few cells, each spread over many workgroups
     that exchange partial sums (3 cells of ~600 000 photons); more cells than half the
     compute units, one workgroup each (150 cells of ~17 000); and a few hundred cells of
     5 000 to 9 000 photons (three-day cells of a bright source), which also get a
-    workgroup each because one wavefront per cell would stream them too slowly."""
+    workgroup each because one wavefront per cell would stream them too slowly; and cells of
+    3 100 to 6 400, beyond the registers of a wavefront, whose fit one wavefront streams
+    four loads at a time."""
     from godot_amd import ops
     dev = _dev()
     rng = np.random.default_rng(5 + len(shape))
@@ -453,9 +455,13 @@ def test_very_large_cells_by_layout(shape):
     elif shape == 'one_workgroup':
         cnt = rng.integers(16500, 18000, 150).astype(np.int64)
         check = [0, 7, 77, 149]
-    else:
+    elif shape == 'moderate_few':
         cnt = rng.integers(5200, 9000, 300).astype(np.int64)
         check = [0, 13, 150, 299]
+    else:
+        cnt = rng.integers(3100, 6400, 300).astype(np.int64)
+        cnt[:4] = [3100, 3101, 3102, 3103]      # ragged ends of the four-load batches
+        check = [0, 1, 2, 3, 150, 299]
     off = np.append(0, np.cumsum(cnt)).astype(np.int64)
     we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
     S = cnt * 0.17 * rng.choice([0.4, 1.0, 2.5], len(cnt))
