@@ -403,6 +403,47 @@ def test_very_large_cells(variant):
             assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), c
 
 
+@pytest.mark.parametrize('variant', ['swap', 'beta', 'guess'])
+def test_streamed_cells_in_the_variants_of_the_fit(variant):
+    """Cells of 3 100 to 6 400 photons, which one wavefront streams in every pass of the fit:
+    the complemented weights, a background level other than 1 and a guess other than 1."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(len(variant) + 57)
+    cnt = rng.integers(3100, 6400, 300).astype(np.int64)
+    cnt[:4] = [3100, 3101, 3102, 3103]
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+    S = cnt * 0.17 * rng.choice([0.4, 1.0, 2.5], len(cnt))
+    B = S * 5
+    wd, od = torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev)
+    Sd, Bd = torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev)
+    kw = {}
+    guess, beta = 1.0, 1.0
+    if variant == 'swap':
+        cr = ops.CellRanges.from_offsets(1 - wd, od, Bd, Sd)
+        kw['swap'] = True
+    else:
+        cr = ops.CellRanges.from_offsets(wd, od, Sd, Bd)
+    if variant == 'beta':
+        beta = kw['beta'] = 1.6
+    if variant == 'guess':
+        guess = kw['guess'] = 0.3
+    alpha, ts, flags = ops.cell_fit(cr, **kw)
+    alpha, ts = alpha.cpu().numpy(), ts.cpu().numpy()
+    assert not (flags.cpu().numpy() & 0x10).any()
+    tol = RTOL * (100 if variant == 'swap' else 1)
+    with np.errstate(all='ignore'):
+        for c in [0, 1, 2, 3, 77, 150, 299]:
+            w = we[off[c]:off[c + 1]]
+            cl = orc.CellLike(w, S[c], S[c] / B[c])
+            a = cl.get_max(guess=guess, beta=beta)
+            t = cl.get_ts(a)
+            sc = max(1.0, np.abs(np.log1p(-w)).sum())
+            assert abs(alpha[c] - a) <= tol * max(1, abs(a)), (c, alpha[c], a)
+            assert abs(ts[c] - t) <= tol * max(sc, abs(t)), (c, ts[c], t)
+
+
 def test_zero_alpha_is_flagged_however_it_was_reached():
     """alpha-hat = 0 comes about in two ways: the derivative at zero is negative, or a
     Newton/Halley iterate is clamped to the boundary (core.py:671, 680).  Both carry the
