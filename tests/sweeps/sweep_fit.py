@@ -14,7 +14,7 @@ for conf in range(nconf):
     if time.time() - t_start > budget:
         break
     rng = np.random.default_rng(1000 * seed0 + conf)
-    mu = float(rng.choice([0.3, 1, 3, 6, 10, 15, 23, 30, 45, 60, 90, 150, 300, 800, 3000]))
+    mu = float(rng.choice([0.3, 1, 3, 6, 10, 15, 23, 30, 45, 60, 90, 150, 300, 800, 3000, 4500, 7000]))
     cdist = rng.choice(['poisson', 'geometric', 'constant', 'bimodal'])
     wdist = rng.choice(['b0315', 'b22', 'uniform', 'near1', 'tiny', 'mixed'])
     ncell = int(min(20000, max(60, 600000 / mu)))
