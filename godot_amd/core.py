@@ -705,7 +705,10 @@ class CellsLogLikelihood(object):
             # core.py:1231-1245: beta guess from the profile, joint refit, profile TS
             bg, _, bf = ops.cell_beta_max(self._cr, ag, swap=self._swap, want_logl=False)
             _raise_unconverged_beta(bf, self.allow_failed_cells, ag)
-            aopt, _, _, _ = ops.cell_fit_joint(self._cr, guess_a=ag, guess_b=bg, swap=self._swap)
+            # a joint fit that stops short is no error in the reference either (it prints a
+            # warning, core.py:561, 619, 628): only ranges outside the photon arrays are
+            aopt, _, _, jf = ops.cell_fit_joint(self._cr, guess_a=ag, guess_b=bg, swap=self._swap)
+            _raise_bad_ranges(jf)
             _, lp1, bf1 = ops.cell_beta_max(self._cr, aopt, swap=self._swap)
             _, lp0, bf0 = ops.cell_beta_max(self._cr, 0.0, swap=self._swap)
             _raise_unconverged_beta(bf1 | bf0, self.allow_failed_cells, aopt)
@@ -799,7 +802,12 @@ class CellsLogLikelihood(object):
         cr = blocks.ranges()
         if self.profile_background:
             aopt, _, _, fl = ops.cell_fit_joint(cr, swap=self._swap)
-            dom, cod, _ = ops.cell_logpdf_profile(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
+            _raise_bad_ranges(fl)
+            dom, cod, pf = ops.cell_logpdf_profile(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
+            if not self.allow_failed_cells and bool((pf & 0x10).any().cpu()):
+                # get_beta_max out of restarts or brentq without a sign change inside
+                # _get_logpdf_profile: the reference raises out of get_flux (core.py:816-819, 959-964)
+                raise ValueError('Did not converge while profiling the background of a block')
             _, lp1, bf1 = ops.cell_beta_max(cr, aopt, swap=self._swap)
             _, lp0, bf0 = ops.cell_beta_max(cr, 0.0, swap=self._swap)
             _raise_unconverged_beta(bf1 | bf0, self.allow_failed_cells, aopt)

@@ -360,39 +360,12 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
                         pr[u] = 1.0;
                         ex[u] = 0;
                     }
-                    int j = 0;
                     if (!swap) {
-                        for (; j + 8 <= n_c; j += 8) {
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const double wj = w[j + k];
-#pragma unroll
-                                for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
-                            }
-#pragma unroll
-                            for (int u = 0; u < LP_PPL; ++u) {
-                                ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
-                                pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
-                            }
-                        }
-                        for (; j < n_c; ++j) {
-                            const double wj = w[j];
-#pragma unroll
-                            for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(am1[u], wj, 1.0);
-                        }
+                        grid_products<LP_PPL>(w, n_c, p.nph - lo_c, pr, ex,
+                                              [&](double wj, int u) { return fma(am1[u], wj, 1.0); });
                     } else {
-                        for (; j < n_c; ++j) {
-                            const double wj = w[j];
-#pragma unroll
-                            for (int u = 0; u < LP_PPL; ++u) pr[u] *= fma(-am1[u], wj, av[u]);
-                            if ((j & 7) == 7) {
-#pragma unroll
-                                for (int u = 0; u < LP_PPL; ++u) {
-                                    ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
-                                    pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
-                                }
-                            }
-                        }
+                        grid_products<LP_PPL>(w, n_c, p.nph - lo_c, pr, ex,
+                                              [&](double wj, int u) { return fma(-am1[u], wj, av[u]); });
                     }
 #pragma unroll
                     for (int u = 0; u < LP_PPL; ++u) {

@@ -635,6 +635,57 @@ __device__ double test_statistic(const CD &cd, double S, double aopt)
     return 2 * (dl - S * aopt);
 }
 
+// Running products over a cell's wave-uniform weights (they arrive by scalar loads):
+// pr[u] *= fac(w_j, u) for every photon j < n and every one of the lane's PPL grid points,
+// mantissas renormalised after every eight factors.  The last n mod 8 weights are asked for
+// in ONE request of eight, which reads on into whatever follows the cell but never beyond
+// the `room` weights that exist from w[0] on; a request per weight makes the wavefront wait
+// out the latency of a scalar load for each of them (3.5 times a cell on average).
+template <int PPL, class FAC>
+__device__ __forceinline__ void grid_products(const double *__restrict__ w, int n, int64_t room,
+                                              double (&pr)[PPL], int (&ex)[PPL], FAC fac)
+{
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double wj = w[j + k];
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) pr[u] *= fac(wj, u);
+        }
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            ex[u] += __builtin_amdgcn_frexp_exp(pr[u]);
+            pr[u] = __builtin_amdgcn_frexp_mant(pr[u]);
+        }
+    }
+    const int rem = n - j;
+    if (rem <= 0) return;
+    if ((int64_t)j + 8 <= room) {
+        double wt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wt[k] = w[j + k];
+        // all eight before the first is used: keeps the compiler from splitting the request
+        // into the part that is always needed and the part that may not be
+        asm volatile("" : "+s"(wt[0]), "+s"(wt[1]), "+s"(wt[2]), "+s"(wt[3]), "+s"(wt[4]), "+s"(wt[5]),
+                          "+s"(wt[6]), "+s"(wt[7]));
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (k < rem) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) pr[u] *= fac(wt[k], u);
+            }
+        }
+    } else {
+        // the last cells of the photon array
+        for (; j < n; ++j) {
+            const double wj = w[j];
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) pr[u] *= fac(wj, u);
+        }
+    }
+}
+
 struct Support {
     double amin, amax, llmax;
 };
