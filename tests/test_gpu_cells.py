@@ -348,6 +348,42 @@ def test_logpdf_sparse_cell_kernels(mean, variant):
     assert ncmp > 60
 
 
+@pytest.mark.parametrize('swap', [False, True])
+def test_logpdf_of_the_last_cells_of_the_photon_array(swap):
+    """The grid evaluation asks for the last n mod 8 weights of a cell in one request of eight,
+    which reads on into the next cell; the cells at the very end of the array have nothing
+    behind them and take their weights one by one.  Every remainder 0 .. 7 at the end of the
+    array, every cell against the oracle."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    for tail in range(0, 20):
+        cnt = np.concatenate([rng.poisson(13, 40), [tail]]).astype(np.int64)
+        off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+        we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+        S = np.maximum(cnt * 0.17 * rng.uniform(0.3, 3, len(cnt)), 0.05)
+        B = S * 5
+        wd, od = torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev)
+        Sd, Bd = torch.from_numpy(S).to(dev), torch.from_numpy(B).to(dev)
+        if swap:
+            cr = ops.CellRanges.from_offsets(1 - wd, od, Bd, Sd)
+        else:
+            cr = ops.CellRanges.from_offsets(wd, od, Sd, Bd)
+        dom, cod, flags = ops.cell_logpdf(cr, dlogl=30, npt=200, swap=swap)
+        dom, cod, flags = dom.cpu().numpy(), cod.cpu().numpy(), flags.cpu().numpy()
+        assert not (flags & 0x10).any()
+        tol = RTOL * (100 if swap else 1)
+        with np.errstate(all='ignore'):
+            for c in range(len(cnt) - 6, len(cnt)):
+                w = we[off[c]:off[c + 1]]
+                d, v = orc.CellLike(w, S[c], S[c] / B[c]).get_logpdf(dlogl=30, npt=200)
+                if np.isnan(d).any() or np.isnan(v).any():
+                    continue
+                sc = max(1.0, np.abs(np.log1p(-w)).sum())
+                assert np.abs(dom[c] - d).max() <= tol * max(1.0, np.abs(d).max()), (tail, c, cnt[c])
+                assert np.abs(cod[c] - v).max() <= tol * max(sc, np.abs(v).max()), (tail, c, cnt[c])
+
+
 @pytest.mark.parametrize('variant', ['plain', 'swap', 'beta', 'guess', 'npt300', 'given'])
 def test_very_large_cells(variant):
     """Cells of tens of thousands of photons (what merged Bayesian blocks are):
