@@ -8,6 +8,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 FIT="--steps 12 --warmup 4 --no-cpu --no-extra"
+# the traced and counted launches have the GPU to themselves: one stream (the plain bench line of
+# step 7 deals its timed steps over three, where launches overlap and each one alone takes longer)
+export GODOT_BENCH_STREAMS=1
 # 1. per-kernel times of the bench command (C4 leg cut to 2^24 trial frequencies to bound the traced run)
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu --nfreq 16777216 > $OUT/bench_under_rocprof.log 2>&1 || exit 1
 # 2. HBM traffic of the fit kernel on the rotating lists: FETCH_SIZE and WRITE_SIZE in passes of their own
@@ -25,7 +28,8 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/fft_w
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/grid_sq -- python3 $R/profiles/grid_once.py > $OUT/grid_sq.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/grid_write -- python3 $R/profiles/grid_once.py > $OUT/grid_write.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/grid_trace -- python3 $R/profiles/grid_once.py > $OUT/grid_trace.log 2>&1 || exit 1
-# 7. the plain bench line (no profiler attached)
+# 7. the plain bench line (no profiler attached), streams as the bench chooses them
+unset GODOT_BENCH_STREAMS
 T0=$SECONDS
 timeout -k 10 600 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 WALL=$((SECONDS - T0))

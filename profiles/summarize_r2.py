@@ -56,7 +56,8 @@ def counters(root, sub, title, match):
 
 def main():
     root = sys.argv[1]
-    kernel_stats(os.path.join(root, 'trace'), 'python3 bench.py --steps 100 --warmup 10 --no-cpu --nfreq 16777216')
+    kernel_stats(os.path.join(root, 'trace'), 'GODOT_BENCH_STREAMS=1 python3 bench.py --steps 100 --warmup 10 --no-cpu --nfreq 16777216  '
+                 '(one stream: every launch has the GPU to itself, as the HIP events of roofline.avg_launch_ms time it)')
     f = counters(root, 'pmc_fetch', 'rocprofv3 --pmc FETCH_SIZE (KB): bench.py --steps 12 --warmup 4 --no-cpu --no-extra', 'cell_fit')
     w = counters(root, 'pmc_write', 'rocprofv3 --pmc WRITE_SIZE (KB), same command', 'cell_fit')
     counters(root, 'pmc_sq', 'rocprofv3 --pmc SQ_* instruction mix of the fit kernel, same command', 'cell_fit')
