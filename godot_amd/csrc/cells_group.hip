@@ -288,6 +288,16 @@ __device__ __noinline__ void slow_cell_fit(const double *wp, int64_t n, bool swa
     if (want_ts && !(fl & GODOT_F_FAILED)) t_out = test_statistic(sc, S, a);
 }
 
+// The test statistic of a restarted cell, as a function of its own: inlined into the loop
+// over a wavefront's restarts, the constants of its logarithm were formed once ahead of the
+// loop and, with no register to spare there, pushed to scratch memory and fetched back --
+// 28 MB of the 37 MB that a C2 launch wrote.
+template <class CD>
+__device__ __noinline__ double test_statistic_apart(CD cd, double S, double aopt)
+{
+    return test_statistic(cd, S, aopt);
+}
+
 template <int L, int R, bool B0, bool INPLACE>
 __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const double *guess, double guess0,
                                                     const double *beta, double beta0, double *alpha,
@@ -441,6 +451,27 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         }
     }
 
+    // results: the first lanes of the groups hand theirs to lanes 0 .. CW-1, which
+    // store whole rows (before the restarts run: what a finished cell puts out then no
+    // longer occupies registers across them, and nothing of it is pushed to scratch memory)
+    if (L > 1) {
+        const int from = (lane * L) & 63;
+        o_a = __shfl(o_a, from, WAVE);
+        if (ts) o_t = __shfl(o_t, from, WAVE);
+        o_fl = __shfl(o_fl | (o_full ? 0x100 : 0) | (o_hand ? 0x200 : 0), from, WAVE);
+        o_full = (o_fl & 0x100) != 0;
+        o_hand = (o_fl & 0x200) != 0;
+        o_fl &= 0xff;
+    }
+    if (lane < CW && cell0 + lane < p.ncell) {
+        const int64_t c = cell0 + lane;
+        if (o_full || o_hand) alpha[c] = o_a;
+        if (o_full) {
+            if (ts) ts[c] = o_t;
+            if (flags) flags[c] = fit_flags(o_fl, o_a);
+        }
+    }
+
     // Restarts in place (about 1 cell in 100 here, one or two per wavefront that has
     // any): four at a time by teams of 16 lanes, which take the cell's weights from
     // the LDS copy -- a fraction of the instructions that sending the whole wavefront
@@ -491,33 +522,13 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
                     b_s = (b_s + 1) - 1;
                 }
                 double t = qnan();
-                if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic(cd, S_s, a);
+                if (ts && !(fl & GODOT_F_FAILED)) t = test_statistic_apart(cd, S_s, a);
                 if (tl == 0) {
                     alpha[c] = isnan(a) ? qnan() : a;
                     if (ts) ts[c] = t;
                     if (flags) flags[c] = fit_flags(fl, a);
                 }
             }
-        }
-    }
-
-    // results: the first lanes of the groups hand theirs to lanes 0 .. CW-1, which
-    // store whole rows
-    if (L > 1) {
-        const int from = (lane * L) & 63;
-        o_a = __shfl(o_a, from, WAVE);
-        if (ts) o_t = __shfl(o_t, from, WAVE);
-        o_fl = __shfl(o_fl | (o_full ? 0x100 : 0) | (o_hand ? 0x200 : 0), from, WAVE);
-        o_full = (o_fl & 0x100) != 0;
-        o_hand = (o_fl & 0x200) != 0;
-        o_fl &= 0xff;
-    }
-    if (lane < CW && cell0 + lane < p.ncell) {
-        const int64_t c = cell0 + lane;
-        if (o_full || o_hand) alpha[c] = o_a;
-        if (o_full) {
-            if (ts) ts[c] = o_t;
-            if (flags) flags[c] = fit_flags(o_fl, o_a);
         }
     }
 
