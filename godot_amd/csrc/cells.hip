@@ -300,7 +300,15 @@ __global__ __launch_bounds__(256) void cell_logpdf_kernel(CellArgs p, const doub
         } else if (aopt_in) {
             a0 = aopt_in[cell];
         } else {
-            a0 = fit_alpha(cd, S, 1.0, 1.0, fl);
+            // the bracketing fallback on a streamed view of the cell: handed the register
+            // copy by reference, it would make every team keep a second copy in scratch memory
+            bool numerical = false;
+            a0 = fit_alpha(cd, S, 1.0, 1.0, fl, &numerical);
+            if (numerical) {
+                StreamCell<LP_T> sc;
+                stream_load(sc, p.we + lo, n, lane, swap);
+                a0 = max_numerical(sc, S, fl);
+            }
             if (fl & GODOT_F_FAILED) bad = true;
         }
         if (lane == 0) {

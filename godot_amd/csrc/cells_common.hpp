@@ -585,8 +585,13 @@ __device__ bool fit_attempt_impl(const CD &cd, double S, double g, double b, dou
 
 // get_max in place: used where a cell's weights are already loaded and no
 // other team can take over its restarts (the profile-grid kernel).
+//   hand_on   not null: when the restarts run out, the bracketing fallback is left to the
+//             caller (*hand_on = true, NaN returned).  max_numerical is a function of its own
+//             and takes the cell by reference, so a cell that is passed to it lives in memory
+//             as well as in registers: for a cell held in tens of registers that is a copy
+//             written to scratch memory by every wavefront, used by almost none.
 template <class CD>
-__device__ double fit_alpha(const CD &cd, double S, double guess, double beta, int &flags)
+__device__ double fit_alpha(const CD &cd, double S, double guess, double beta, int &flags, bool *hand_on = nullptr)
 {
     double g = guess - 1;
     double b = beta - 1;
@@ -601,7 +606,13 @@ __device__ double fit_alpha(const CD &cd, double S, double guess, double beta, i
             }
             return a + 1;
         }
-        if (depth > 2) return max_numerical(cd, S, flags);
+        if (depth > 2) {
+            if (hand_on) {
+                *hand_on = true;
+                return qnan();
+            }
+            return max_numerical(cd, S, flags);
+        }
         g = (a + 1) - 1;
         b = (b + 1) - 1;
     }

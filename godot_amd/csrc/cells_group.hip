@@ -750,17 +750,18 @@ __global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, co
     int state = (have && !bad) ? 0 : 2;
     int fl = (have && bad) ? (GODOT_F_FAILED | GODOT_F_BAD_RANGE) : 0;
     double aopt = qnan();
+    bool numerical = false;
     if (state == 0) {
         if (aopt_in) {
             aopt = aopt_in[cell];
         } else if (!big) {
-            aopt = fit_alpha(gc, S, 1.0, 1.0, fl);
-            if (fl & GODOT_F_FAILED) state = 2;
+            aopt = fit_alpha(gc, S, 1.0, 1.0, fl, &numerical);
         }
     }
-    // big cells: all 64 lanes on one cell at a time
+    // big cells, and cells whose restarts have run out (the bracketing fallback): all 64
+    // lanes on one cell at a time
     if (!aopt_in) {
-        unsigned long long bigs = __ballot((big && state == 0 && q == 0) ? 1 : 0);
+        unsigned long long bigs = __ballot(((big || numerical) && state == 0 && q == 0) ? 1 : 0);
         while (bigs) {
             const int src = __builtin_ctzll(bigs);
             bigs &= bigs - 1;
