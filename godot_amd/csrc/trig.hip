@@ -122,9 +122,10 @@ constexpr int Z_THREADS = 256;
 #ifndef Z_AHEAD
 #define Z_AHEAD 4
 #endif
+constexpr int Z_FOLD = 4096;      // photons between two corrections of the sum of c^2 (a multiple of Z_AHEAD)
 
 // Frequencies per thread.  The sin/cos of a thread's first frequency costs
-// about 50 instructions per photon, a further frequency 4 (m = 1), 7 (m = 2)
+// about 50 instructions per photon, a further frequency 4 (m = 1), 6 (m = 2)
 // or 4m + 1, so J is as large as the registers allow: about 96 running sums
 // (192 VGPRs) at two waves per SIMD; m = 1 keeps four waves (measured best).
 #ifndef Z_JCAP
@@ -152,8 +153,9 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
         sincos_cycles(x, s, c);
         if constexpr (SQ) {
             // Non-negative weights, M == 2.  The phasor carries the amplitude sqrt(w), so that its square is
-            // w exp(2 i phi): harmonic 2 is three multiply-adds on (c, s), with
-            // the sine sum left at half its value until the loop is over.
+            // w exp(2 i phi): harmonic 2 is two multiply-adds on (c, s).  The sine sum is left at half
+            // its value until the loop is over; the cosine sum, w cos 2 phi = 2 c^2 - w, is gathered as
+            // sum c^2, and the caller takes half the weights off it block by block (see below).
             c *= r.sqw;
             s *= r.sqw;
             double cp = fma(c, r.cd, s * r.sd), sp = fma(s, r.cd, -(c * r.sd));
@@ -162,7 +164,6 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
                 acc[k][0][0] = fma(r.sqw, c, acc[k][0][0]);
                 acc[k][0][1] = fma(r.sqw, s, acc[k][0][1]);
                 acc[k][1][0] = fma(c, c, acc[k][1][0]);
-                acc[k][1][0] = fma(-s, s, acc[k][1][0]);
                 acc[k][1][1] = fma(c, s, acc[k][1][1]);
                 if (k + 1 < J) {
                     double cn = fma(r.tcd, c, -cp), sn = fma(r.tcd, s, -sp);
@@ -203,18 +204,48 @@ __device__ __forceinline__ void z2m_accumulate(const PhotonRow *__restrict__ row
     // The rows come by wave-uniform (scalar) loads.  Z_AHEAD of them are requested
     // together, so the wavefront waits out the load latency once per group and not
     // once per photon (at two wavefronts per SIMD nobody else hides it).
-    int64_t i = i0;
-    for (; i + Z_AHEAD <= i1; i += Z_AHEAD) {
-        PhotonRow r[Z_AHEAD];
+    if constexpr (!SQ) {
+        int64_t i = i0;
+        for (; i + Z_AHEAD <= i1; i += Z_AHEAD) {
+            PhotonRow r[Z_AHEAD];
 #pragma unroll
-        for (int u = 0; u < Z_AHEAD; ++u) r[u] = rows[i + u];
+            for (int u = 0; u < Z_AHEAD; ++u) r[u] = rows[i + u];
 #pragma unroll
-        for (int u = 0; u < Z_AHEAD; ++u) one(r[u]);
-    }
-    for (; i < i1; ++i) one(rows[i]);
-    if constexpr (SQ) {
+            for (int u = 0; u < Z_AHEAD; ++u) one(r[u]);
+        }
+        for (; i < i1; ++i) one(rows[i]);
+    } else {
+        // sum c^2 runs ahead of the sum it stands for by half the weights gone by.  They are
+        // taken off after every block of Z_FOLD photons, so that the running sums stay as small
+        // as the trig sums themselves plus one block's weights and keep their low bits (left to
+        // the end, a sum of 10^6 photons would carry 10^5 and lose four digits of the 10^2 that
+        // matter).
+        for (int64_t b0 = i0; b0 < i1; b0 += Z_FOLD) {
+            const int64_t b1 = b0 + Z_FOLD < i1 ? b0 + Z_FOLD : i1;
+            double wblk = 0.0;
+            int64_t i = b0;
+            for (; i + Z_AHEAD <= b1; i += Z_AHEAD) {
+                PhotonRow r[Z_AHEAD];
 #pragma unroll
-        for (int k = 0; k < J; ++k) acc[k][1][1] += acc[k][1][1];
+                for (int u = 0; u < Z_AHEAD; ++u) r[u] = rows[i + u];
+#pragma unroll
+                for (int u = 0; u < Z_AHEAD; ++u) {
+                    wblk += r[u].w;
+                    one(r[u]);
+                }
+            }
+            for (; i < b1; ++i) {
+                wblk += rows[i].w;
+                one(rows[i]);
+            }
+#pragma unroll
+            for (int k = 0; k < J; ++k) acc[k][1][0] = fma(-0.5, wblk, acc[k][1][0]);
+        }
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+            acc[k][1][0] += acc[k][1][0];
+            acc[k][1][1] += acc[k][1][1];
+        }
     }
 }
 
