@@ -291,7 +291,8 @@ __device__ __noinline__ void slow_cell_fit(const double *wp, int64_t n, bool swa
 // The test statistic of a restarted cell, as a function of its own: inlined into the loop
 // over a wavefront's restarts, the constants of its logarithm were formed once ahead of the
 // loop and, with no register to spare there, pushed to scratch memory and fetched back --
-// 28 MB of the 37 MB that a C2 launch wrote.
+// 28 MB of the 37 MB that a launch over 4.4e5 ten-minute cells (1e7 photons) wrote, where its
+// results are 9 MB.
 template <class CD>
 __device__ __noinline__ double test_statistic_apart(CD cd, double S, double aopt)
 {
@@ -918,7 +919,7 @@ namespace godot_detail {
 // decides: their sizes spread wider than Poisson (the exposure of a cell varies along the
 // orbit; ten-minute cells of 22.6 photons on average have a standard deviation of 7, not
 // 4.8), and every photon beyond the slots costs a trip through the tail loops in all five
-// passes, so the two-lane shapes are chosen to hold the mean plus three sigma (C2: 2 x 20
+// passes, so the two-lane shapes are chosen to hold the mean plus three sigma (ten-minute cells of 1e7 photons in ten years: 2 x 20
 // slots, 41.7 us against 49.3 us with 2 x 16).  Larger cells take 4 to 64 lanes: measured
 // on 10^7 photons these shapes fit cells of 40 to 1 400 photons in 35-45 us and form their
 // profile grids in 0.32-0.52 ms, where the team-per-cell kernels of cells.hip take 40-66 us
