@@ -348,6 +348,36 @@ def test_logpdf_sparse_cell_kernels(mean, variant):
     assert ncmp > 60
 
 
+def test_fits_on_different_streams_give_the_same_bits():
+    """Independent calls may overlap on different streams (the entry points keep no state
+    between calls): fits and profile grids of three lists launched on three streams, several
+    times over, equal the same calls made one after the other to the last bit."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    crs = []
+    for mean, ncell in ((22, 40000), (9, 60000), (120, 9000)):
+        cnt = rng.poisson(mean, ncell).astype(np.int64)
+        off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+        we = np.clip(rng.beta(0.3, 1.5, int(off[-1])), 1e-6, 1 - 1e-6)
+        S = np.maximum(cnt * 0.17 * rng.uniform(0.3, 3, ncell), 0.05)
+        crs.append(ops.CellRanges.from_offsets(torch.from_numpy(we).to(dev), torch.from_numpy(off).to(dev),
+                                               torch.from_numpy(S).to(dev), torch.from_numpy(S * 5).to(dev)))
+    ref = [ops.cell_fit(cr) + ops.cell_logpdf(cr, dlogl=30, npt=50) for cr in crs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in crs]
+    for rep in range(4):
+        outs = []
+        for cr, st in zip(crs, streams):
+            with torch.cuda.stream(st):
+                outs.append(ops.cell_fit(cr) + ops.cell_logpdf(cr, dlogl=30, npt=50))
+        torch.cuda.synchronize()
+        for got, want in zip(outs, ref):
+            for g, w in zip(got, want):
+                assert torch.equal(g.view(torch.int64) if g.dtype == torch.float64 else g,
+                                   w.view(torch.int64) if w.dtype == torch.float64 else w)
+
+
 @pytest.mark.parametrize('swap', [False, True])
 def test_logpdf_of_the_last_cells_of_the_photon_array(swap):
     """The grid evaluation asks for the last n mod 8 weights of a cell in one request of eight,
