@@ -999,14 +999,18 @@ class Data(object):
             return ops.exposure_at_rows(self.TSTART, self.TSTOP, self.exposure, self.sexposure,
                                         self.bexposure, self.LIVETIME, tab, t, cumulative=cumulative,
                                         deadtime_too=deadtime_too)
+        return ops.exposure_at(self.TSTART, self.TSTOP, self.exposure, self.LIVETIME,
+                               self.S / self.E, self.B / self.E, self._plain_exposure_table(), t,
+                               cumulative=cumulative, deadtime_too=deadtime_too)
+
+    def _plain_exposure_table(self):
+        """Running sums of the exposure table (no scalers applied): built once, reused by
+        every query."""
         if self._exposure_table is None:
-            # running sums of the exposure table: built once, reused by every query
             self._exposure_table = ops.exposure_table(
                 self.TSTART, self.TSTOP, self.exposure, self.LIVETIME, self.S / self.E,
                 self.B / self.E)
-        return ops.exposure_at(self.TSTART, self.TSTOP, self.exposure, self.LIVETIME,
-                               self.S / self.E, self.B / self.E, self._exposure_table, t,
-                               cumulative=cumulative, deadtime_too=deadtime_too)
+        return self._exposure_table
 
     def get_deadtime(self, times):
         """Cumulative dead time at the given times (reference core.py:1845-1847)."""
@@ -1204,16 +1208,9 @@ class Data(object):
         lo = torch.arange(nph, dtype=I64, device=dev)
         return CellBatch(we, ti, lo, lo + 1, starts, stops, sexp, bexp)
 
-    def get_cells(self, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True,
-                  time_series_only=False, use_barycenter=True, randomize=False, seed=None,
-                  src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
-                  minimum_fractional_exposure=0, quiet=False):
-        if use_barycenter and not (hasattr(self, '_t2b') and hasattr(self, '_b2t')):
-            raise NotImplementedError(
-                'use_barycenter=True needs the time converters that the reference builds from '
-                'its astropy ephemeris (bary.py); hand them in with '
-                'set_barycenter_converters(topo2bary, bary2topo), or pass use_barycenter=False')
-        ft1_is_bary = self.timeref == 'SOLARSYSTEM'
+    def _clip_span(self, tstart, tstop, quiet):
+        """The requested span as METs, clipped to the exposure table (reference
+        core.py:2040-2057)."""
         if tstart is None:
             tstart = self._t0
         tstart = float(infer_met(tstart))
@@ -1230,6 +1227,31 @@ class Data(object):
                 print('Warning: Stop time follows end of exposure.')
                 print('Will clip to MET=%.2f.' % (self._t1))
             tstop = self._t1
+        return tstart, tstop
+
+    def _uniform_cells(self, tstart, tstop, tcell, quiet):
+        """(first edge, last time, cell length, number of cells) of get_cells without
+        barycentring (reference core.py:2064-2071): whole cells only, one cell when the span
+        is shorter than a cell."""
+        tstart, tstop = self._clip_span(tstart, tstop, quiet)
+        ncell = int((tstop - tstart) / tcell)
+        if ncell == 0:
+            tcell = tstop - tstart
+            ncell = 1
+        assert(tstart + ncell * tcell <= tstop)
+        return tstart, tstop, tcell, ncell
+
+    def get_cells(self, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True,
+                  time_series_only=False, use_barycenter=True, randomize=False, seed=None,
+                  src_scaler=None, bkg_scaler=None, src_injector=None, minimum_exposure=3e4,
+                  minimum_fractional_exposure=0, quiet=False):
+        if use_barycenter and not (hasattr(self, '_t2b') and hasattr(self, '_b2t')):
+            raise NotImplementedError(
+                'use_barycenter=True needs the time converters that the reference builds from '
+                'its astropy ephemeris (bary.py); hand them in with '
+                'set_barycenter_converters(topo2bary, bary2topo), or pass use_barycenter=False')
+        ft1_is_bary = self.timeref == 'SOLARSYSTEM'
+        tstart, tstop = self._clip_span(tstart, tstop, quiet)
 
         if use_barycenter:
             tstart, tstop = (float(x) for x in self._topo2bary([tstart, tstop]))
@@ -1414,34 +1436,48 @@ class SourceBatch(object):
         return [rows[int(o[k]):int(o[k + 1])] for k in range(len(o) - 1)]
 
 
-def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True):
+def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
+                    per_source_calls=False):
     """Data.get_cells(tstart, tstop, tcell, use_barycenter=False) for every Data object of
     `sources`, as one SourceBatch.  Every source is binned on its own edges and exposure
-    table; the zero-exposure cells of all of them are then dropped by ONE selection, so the
-    host waits for the device once per batch, not once per source (a thousand sources at
-    45 us a launch would otherwise be bound by those waits)."""
+    table, all of them by the same two launches (ops.bin_sources); the zero-exposure cells of
+    all of them are then dropped by ONE selection, so the host waits for the device once per
+    batch, not once per source, and the number of launches does not grow with the number of
+    sources (a thousand sources at ten launches each would be bound by issuing them).
+    per_source_calls=True, and any source with scalers applied, takes the calls one source
+    at a time instead: the same bits."""
     if tcell is None:
         raise ValueError('get_cells_batch needs a cell length')
     if not sources:
         raise ValueError('no sources')
     dev = sources[0].device
-    per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=False,
-                       use_barycenter=False, quiet=quiet) for d in sources]
-    nph = np.array([b.we.numel() for b in per], dtype=np.int64)
-    ncl = np.array([len(b) for b in per], dtype=np.int64)
-    poff = np.concatenate([[0], np.cumsum(nph)])
-    cat = lambda name: torch.cat([getattr(b, name) for b in per])
-    we, ti = cat('we'), cat('ti')
-    shift = torch.repeat_interleave(torch.from_numpy(poff[:-1]).to(dev), torch.from_numpy(ncl).to(dev))
-    lo, hi = cat('lo') + shift, cat('hi') + shift
-    starts, stops, sexp, bexp = cat('starts'), cat('stops'), cat('sexp'), cat('bexp')
-    source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
+    if per_source_calls or any(d.sexposure is not None for d in sources):
+        per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=False,
+                           use_barycenter=False, quiet=quiet) for d in sources]
+        nph = np.array([b.we.numel() for b in per], dtype=np.int64)
+        ncl = np.array([len(b) for b in per], dtype=np.int64)
+        poff = np.concatenate([[0], np.cumsum(nph)])
+        cat = lambda name: torch.cat([getattr(b, name) for b in per])
+        shift = torch.repeat_interleave(torch.from_numpy(poff[:-1]).to(dev), torch.from_numpy(ncl).to(dev))
+        lo, hi = cat('lo') + shift, cat('hi') + shift
+        starts, stops, sexp, bexp = cat('starts'), cat('stops'), cat('sexp'), cat('bexp')
+        source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
+    else:
+        desc = []
+        for d in sources:
+            t0, t1, tc, nc = d._uniform_cells(tstart, tstop, tcell, quiet)
+            desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
+                             table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
+                             t0=t0, tcell=tc, ncell=nc))
+        starts, stops, _, sexp, bexp, _, lo, hi, source = ops.bin_sources(desc)
+        ncl = np.array([s['ncell'] for s in desc], dtype=np.int64)
+    we, ti = torch.cat([d.we for d in sources]), torch.cat([d.ti for d in sources])
     if trim_zero_exposure:
         # a cell has exposure exactly when it has source exposure (sexp = S / E * exp, S > 0)
         keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch
         lo, hi, starts, stops, sexp, bexp, source = ops.gather_columns(
             [c.contiguous() for c in (lo, hi, starts, stops, sexp, bexp, source)], keep)
-        ncl = torch.bincount(source, minlength=len(per)).cpu().numpy()
+        ncl = torch.bincount(source, minlength=len(sources)).cpu().numpy()
     cells = CellBatch(we, ti, lo.contiguous(), hi.contiguous(), starts, stops, sexp, bexp)
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
 

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, in
     }
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int64_t cs_chunks(int64_t n) { return (n + CS_CHUNK - 1) / CS_CHUNK; }
 inline size_t cs_scratch_bytes(int64_t n)
 {
@@ -781,10 +781,27 @@ __global__ void exposure_rows_kernel(ExposureLoad ld, int64_t n, ExpRow *rows)
     rows[i] = ExpRow{ld.tstart[i], ld.tstop[i], x.a, x.b, x.c, x.d};
 }
 
-// cumulative exposures at the query times: core.py:1806-1832
-__global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, const Quad *cum,
-                                                             const ExpRow *rows, int64_t n_ft2,
-                                                             const double *times, int64_t n_t, Quad *at)
+// Where a kernel's sorted values (query times, cell stops) come from: an array, or the
+// uniform cell edges first + i, i = 0, 1, ..., formed as numpy forms tstart + arange(n) * tcell
+// (core.py:2071): the product rounded, then the sum rounded.
+struct ArrayAt {
+    const double *p;
+    __device__ __forceinline__ double operator()(int64_t i) const { return p[i]; }
+};
+struct UniformEdge {
+    double t0, tcell;
+    int64_t first;
+    __device__ __forceinline__ double operator()(int64_t i) const
+    {
+        return __dadd_rn(__dmul_rn((double)(i + first), tcell), t0);
+    }
+};
+
+// cumulative exposures at the query times: core.py:1806-1832.  Called by every thread of a
+// 256-thread workgroup (it synchronises); the workgroup serves queries 256 * blockIdx.x ...
+template <class TimeAt>
+__device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, const Quad *cum, const ExpRow *rows,
+                                                    int64_t n_ft2, const TimeAt times, int64_t n_t, Quad *at)
 {
     // sorted queries (cell edges): the rows of the workgroup's first and last query bracket
     // the rows of all the others; those two are searched for by a wavefront each
@@ -795,7 +812,7 @@ __global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, co
     const int64_t kl = (kb + blockDim.x < n_t ? kb + blockDim.x : n_t) - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
-        const double tb = times[kb];
+        const double tb = times(kb);
         const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tb);
         if (lane == 0) {
             s_t[0] = tb;
@@ -803,7 +820,7 @@ __global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, co
         }
     }
     if (wave == (int)((kl - kb) >> 6)) {
-        const double tl = times[kl];
+        const double tl = times(kl);
         const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tl);
         if (lane == 0) {
             s_t[1] = tl;
@@ -812,7 +829,7 @@ __global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, co
     }
     __syncthreads();
     if (k >= n_t) return;
-    const double t = times[k];
+    const double t = times(k);
     int64_t idx;
     if (s_t[0] <= t && t <= s_t[1]) {
         // The rows of a spacecraft file are evenly spaced but for the gaps: the row is guessed
@@ -846,6 +863,13 @@ __global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, co
                  __dsub_rn(c.c, __dmul_rn(r.be, frac)), __dsub_rn(c.d, __dmul_rn(r.dead, frac))};
 }
 
+__global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, const Quad *cum,
+                                                             const ExpRow *rows, int64_t n_ft2,
+                                                             const double *times, int64_t n_t, Quad *at)
+{
+    exposure_query_body(ld, cum, rows, n_ft2, ArrayAt{times}, n_t, at);
+}
+
 __global__ void exposure_out_kernel(const Quad *at, int64_t n_out, int cumulative, double *o_exp,
                                     double *o_sexp, double *o_bexp, double *o_dead)
 {
@@ -862,10 +886,12 @@ __global__ void exposure_out_kernel(const Quad *at, int64_t n_out, int cumulativ
     if (o_dead) o_dead[k] = v.d;
 }
 
-// photon range of every cell (see godot_bin_photons in the header)
-__global__ __launch_bounds__(256) void bin_photons_kernel(const double *ti, int64_t nph, double start0,
-                                                          const double *stops, int64_t ncell, int64_t *lo,
-                                                          int64_t *hi, int64_t *counts)
+// photon range of every cell (see godot_bin_photons in the header); `shift` is added to the
+// indices written.  Called by every thread of a 256-thread workgroup (it synchronises).
+template <class StopAt>
+__device__ __forceinline__ void bin_photons_body(const double *ti, int64_t nph, double start0, const StopAt stops,
+                                                 int64_t ncell, int64_t *lo, int64_t *hi, int64_t *counts,
+                                                 int64_t shift)
 {
     // one search per cell: where its stop falls among the photon times; a cell starts where
     // the cell before it ends, which the neighbouring thread has found.  The stops are
@@ -876,18 +902,18 @@ __global__ __launch_bounds__(256) void bin_photons_kernel(const double *ti, int6
     const int64_t cl = (cb + blockDim.x < ncell ? cb + blockDim.x : ncell) - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {   // where the workgroup's first cell starts
-        const int64_t r = (cb == 0) ? bound_by_wave<false>(ti, nph, start0) : bound_by_wave<true>(ti, nph, stops[cb - 1]);
+        const int64_t r = (cb == 0) ? bound_by_wave<false>(ti, nph, start0) : bound_by_wave<true>(ti, nph, stops(cb - 1));
         if (lane == 0) ends[0] = r;
     }
     if (wave == (int)((cl - cb) >> 6)) {   // where its last cell ends
-        const int64_t r = (cl == ncell - 1) ? bound_by_wave<false>(ti, nph, stops[cl]) : bound_by_wave<true>(ti, nph, stops[cl]);
+        const int64_t r = (cl == ncell - 1) ? bound_by_wave<false>(ti, nph, stops(cl)) : bound_by_wave<true>(ti, nph, stops(cl));
         if (lane == 0) ends[cl - cb + 1] = r;
     }
     __syncthreads();
     if (c < cl) {
-        const double sc = stops[c];
+        const double sc = stops(c);
         // holds for sorted stops; a thread for which it does not searches the whole list
-        const bool bracketed = (cb == 0 || stops[cb - 1] <= sc) && sc < stops[cl];
+        const bool bracketed = (cb == 0 || stops(cb - 1) <= sc) && sc < stops(cl);
         const int64_t wlo = cb == 0 ? 0 : ends[0];   // the first cell's start may lie beyond its stop
         const int64_t whi = ends[cl - cb + 1];
         ends[threadIdx.x + 1] =
@@ -898,9 +924,16 @@ __global__ __launch_bounds__(256) void bin_photons_kernel(const double *ti, int6
     const int64_t l = ends[threadIdx.x];
     int64_t h = ends[threadIdx.x + 1];
     if (h < l) h = l;   // start0 beyond the first stop: empty first cell
-    lo[c] = l;
-    hi[c] = h;
+    lo[c] = l + shift;
+    hi[c] = h + shift;
     if (counts) counts[c] = h - l;
+}
+
+__global__ __launch_bounds__(256) void bin_photons_kernel(const double *ti, int64_t nph, double start0,
+                                                          const double *stops, int64_t ncell, int64_t *lo,
+                                                          int64_t *hi, int64_t *counts)
+{
+    bin_photons_body(ti, nph, start0, ArrayAt{stops}, ncell, lo, hi, counts, 0);
 }
 
 struct MaskLoad {
@@ -1006,8 +1039,52 @@ __global__ void rescale_weights_kernel(const double *w, const double *a, double 
 
 // the table: running sums (32 bytes a row), the rows as the queries read them (48 bytes a
 // row), then what the parallel scan needs while the sums are built
-inline size_t table_sums_bytes(int64_t n) { return align256(sizeof(Quad) * (size_t)n); }
+__host__ __device__ inline size_t table_sums_bytes(int64_t n) { return align256(sizeof(Quad) * (size_t)n); }
 inline size_t table_rows_bytes(int64_t n) { return align256(sizeof(ExpRow) * (size_t)n); }
+
+// Many sources at once (see godot_bin_sources in the header): blockIdx.y is the source, counted
+// from `first`; its descriptor says where its tables and photons are and where its cells go.
+// Pass one: the running sums at the ncell + 1 edges of every source (source k's stand at
+// at[cell_offset + k ...], one more entry than it has cells).
+__global__ __launch_bounds__(256) void sources_query_kernel(const godot_source_cells *src, int64_t first, Quad *at)
+{
+    const int64_t k = first + blockIdx.y;
+    const godot_source_cells s = src[k];
+    const int64_t n_t = s.ncell + 1;
+    if (s.ncell <= 0 || (int64_t)blockIdx.x * blockDim.x >= n_t) return;   // the whole workgroup
+    ExposureLoad ld{s.tstart, s.tstop, s.exposure, s.livetime, s.s_over_e, s.b_over_e, s.sexposure, s.bexposure};
+    exposure_query_body(ld, (const Quad *)s.table,
+                        (const ExpRow *)((const char *)s.table + table_sums_bytes(s.n_ft2)), s.n_ft2,
+                        UniformEdge{s.t0, s.tcell, 0}, n_t, at + s.cell_offset + k);
+}
+
+// Pass two: the photon range of every cell, the exposures between its edges (differences of
+// pass one's sums, as exposure_out_kernel forms them), its edges and its source.
+__global__ __launch_bounds__(256) void sources_cells_kernel(const godot_source_cells *src, int64_t first,
+                                                            const Quad *at, double *starts, double *stops,
+                                                            double *o_exp, double *o_sexp, double *o_bexp,
+                                                            double *o_dead, int64_t *lo, int64_t *hi,
+                                                            int64_t *source)
+{
+    const int64_t k = first + blockIdx.y;
+    const godot_source_cells s = src[k];
+    if ((int64_t)blockIdx.x * blockDim.x >= s.ncell) return;   // the whole workgroup
+    const int64_t o = s.cell_offset;
+    const UniformEdge edge{s.t0, s.tcell, 0};
+    bin_photons_body(s.ti, s.nph, edge(0), UniformEdge{s.t0, s.tcell, 1}, s.ncell, lo + o, hi + o,
+                     (int64_t *)nullptr, s.photon_offset);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.ncell) return;
+    const Quad *a = at + o + k;
+    const Quad v = a[c], u = a[c + 1];
+    o_exp[o + c] = u.a - v.a;
+    o_sexp[o + c] = u.b - v.b;
+    o_bexp[o + c] = u.c - v.c;
+    if (o_dead) o_dead[o + c] = u.d - v.d;
+    if (starts) starts[o + c] = edge(c);
+    if (stops) stops[o + c] = edge(c + 1);
+    if (source) source[o + c] = k;
+}
 
 int exposure_table_impl(const ExposureLoad &ld, int64_t n_ft2, void *table, size_t table_bytes,
                         godot_stream_t stream, const char *fn)
@@ -1201,6 +1278,63 @@ extern "C" int godot_bin_photons(const double *ti, int64_t nph, double start0, c
     hipLaunchKernelGGL(bin_photons_kernel, dim3((unsigned)ceil_div(ncell, 256)), dim3(256), 0,
                        (hipStream_t)stream, ti, nph, start0, stops, ncell, lo, hi, counts);
     GODOT_LAUNCH_CHECK("godot_bin_photons");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_bin_sources_workspace_bytes(int64_t nsrc, int64_t total_cells)
+{
+    if (nsrc < 0 || total_cells < 0) return 0;
+    return align256(sizeof(godot_source_cells) * (size_t)nsrc) + align256(sizeof(Quad) * (size_t)(total_cells + nsrc));
+}
+
+extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc, int64_t total_cells,
+                                 double *starts, double *stops, double *out_exp, double *out_sexp,
+                                 double *out_bexp, double *out_dead, int64_t *lo, int64_t *hi, int64_t *source,
+                                 void *workspace, size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(nsrc >= 0 && total_cells >= 0, GODOT_E_INVALID, "godot_bin_sources: negative size");
+    if (nsrc == 0) return GODOT_OK;
+    GODOT_REQUIRE(sources, GODOT_E_INVALID, "godot_bin_sources: null descriptor table");
+    // the descriptors are host memory: everything the kernels will index by is checked here
+    int64_t end = 0, max_ncell = 0;
+    for (int64_t k = 0; k < nsrc; ++k) {
+        const godot_source_cells &s = sources[k];
+        GODOT_REQUIRE(s.n_ft2 > 0 && s.nph >= 0 && s.ncell >= 0, GODOT_E_INVALID,
+                      "godot_bin_sources: source %lld: bad sizes", (long long)k);
+        GODOT_REQUIRE(s.tstart && s.tstop && s.exposure && s.livetime && s.table && (s.ti || s.nph == 0),
+                      GODOT_E_INVALID, "godot_bin_sources: source %lld: null pointer", (long long)k);
+        GODOT_REQUIRE((s.sexposure == nullptr) == (s.bexposure == nullptr), GODOT_E_INVALID,
+                      "godot_bin_sources: source %lld: one rescaled exposure without the other", (long long)k);
+        GODOT_REQUIRE(s.tcell > 0, GODOT_E_INVALID, "godot_bin_sources: source %lld: cell length must be positive",
+                      (long long)k);
+        GODOT_REQUIRE(s.cell_offset >= end && s.cell_offset + s.ncell <= total_cells, GODOT_E_INVALID,
+                      "godot_bin_sources: source %lld: its cells [%lld, %lld) overlap the source before or pass "
+                      "total_cells", (long long)k, (long long)s.cell_offset, (long long)(s.cell_offset + s.ncell));
+        end = s.cell_offset + s.ncell;
+        if (s.ncell > max_ncell) max_ncell = s.ncell;
+    }
+    if (max_ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(out_exp && out_sexp && out_bexp && lo && hi, GODOT_E_INVALID, "godot_bin_sources: null output");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_bin_sources_workspace_bytes(nsrc, total_cells),
+                  GODOT_E_WORKSPACE, "godot_bin_sources: workspace smaller than godot_bin_sources_workspace_bytes");
+    hipStream_t st = (hipStream_t)stream;
+    godot_source_cells *d_src = (godot_source_cells *)workspace;
+    Quad *at = (Quad *)((char *)workspace + align256(sizeof(godot_source_cells) * (size_t)nsrc));
+    // pageable host memory: the call returns once the table has been staged, the caller may reuse it
+    GODOT_REQUIRE(hipMemcpyAsync(d_src, sources, sizeof(godot_source_cells) * (size_t)nsrc, hipMemcpyHostToDevice,
+                                 st) == hipSuccess,
+                  GODOT_E_LAUNCH, "godot_bin_sources: copy of the descriptor table failed");
+    constexpr int64_t MAX_Y = 65535;
+    for (int64_t first = 0; first < nsrc; first += MAX_Y) {
+        const unsigned ny = (unsigned)(nsrc - first < MAX_Y ? nsrc - first : MAX_Y);
+        hipLaunchKernelGGL(sources_query_kernel, dim3((unsigned)ceil_div(max_ncell + 1, 256), ny), dim3(256), 0, st,
+                           (const godot_source_cells *)d_src, first, at);
+        hipLaunchKernelGGL(sources_cells_kernel, dim3((unsigned)ceil_div(max_ncell, 256), ny), dim3(256), 0, st,
+                           (const godot_source_cells *)d_src, first, (const Quad *)at, starts, stops, out_exp,
+                           out_sexp, out_bexp, out_dead, lo, hi, source);
+    }
+    GODOT_LAUNCH_CHECK("godot_bin_sources");
     return GODOT_OK;
 }
 

@@ -6,6 +6,8 @@ current stream of the tensors' device and returns without synchronising.
 """
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -369,6 +371,70 @@ def bin_photons(ti, start0, stops):
         _lib.call('godot_bin_photons', _p(ti), ti.numel(), float(start0), _p(stops), n, _p(lo),
                   _p(hi), _p(counts), _stream(dev))
     return lo, hi, counts
+
+
+# one record per source, field for field the C struct godot_source_cells (all fields 8 bytes)
+SOURCE_CELLS = np.dtype([(n, 'u8') for n in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure',
+                                             'table', 'ti')]
+                        + [('n_ft2', 'i8'), ('nph', 'i8'), ('s_over_e', 'f8'), ('b_over_e', 'f8'), ('t0', 'f8'),
+                           ('tcell', 'f8'), ('ncell', 'i8'), ('cell_offset', 'i8'), ('photon_offset', 'i8')])
+
+
+def bin_sources(sources, deadtime_too=False):
+    """Uniform cells of many sources in two launches.  `sources`: one dict per source with the
+    device tensors 'tstart', 'tstop', 'exposure', 'livetime', 'table' (exposure_table of those
+    rows), 'ti' (time-sorted photon times), optionally 'sexposure' and 'bexposure' (with the
+    exposure_table_rows table), and the numbers 's_over_e', 'b_over_e', 't0', 'tcell', 'ncell'.
+    The cells of the sources follow one another in the outputs, and lo/hi index the
+    concatenation of the photon lists.  Returns (starts, stops, exp, sexp, bexp, dead or None,
+    lo, hi, source) over all cells."""
+    if not sources:
+        raise ValueError('no sources')
+    dev = sources[0]['ti'].device
+    rec = np.zeros(len(sources), dtype=SOURCE_CELLS)
+    cells = photons = 0
+    for k, s in enumerate(sources):
+        n_ft2 = s['tstart'].numel()
+        for nm in ('tstart', 'tstop', 'exposure', 'livetime'):
+            _dev_check(s[nm], F64, nm)
+            if s[nm].numel() != n_ft2:
+                raise ValueError('source %d: the exposure table columns must have equal lengths' % k)
+            rec[nm][k] = s[nm].data_ptr()
+        if (s.get('sexposure') is None) != (s.get('bexposure') is None):
+            raise ValueError('source %d: sexposure and bexposure come together' % k)
+        for nm in ('sexposure', 'bexposure'):
+            if s.get(nm) is not None:
+                _dev_check(s[nm], F64, nm)
+                if s[nm].numel() != n_ft2:
+                    raise ValueError('source %d: the exposure table columns must have equal lengths' % k)
+                rec[nm][k] = s[nm].data_ptr()
+        _dev_check(s['ti'], F64, 'ti')
+        if s['ti'].device != dev or s['tstart'].device != dev:
+            raise ValueError('source %d: all sources of a batch live on one device' % k)
+        if s['table'].device != dev or s['table'].numel() < _lib.lib.godot_exposure_table_bytes(n_ft2):
+            raise ValueError('source %d: the table does not belong to these %d rows' % (k, n_ft2))
+        ncell = int(s['ncell'])
+        if ncell < 0 or not float(s['tcell']) > 0:
+            raise ValueError('source %d: needs ncell >= 0 and tcell > 0' % k)
+        rec['table'][k] = s['table'].data_ptr()
+        rec['ti'][k] = s['ti'].data_ptr()
+        rec['n_ft2'][k], rec['nph'][k] = n_ft2, s['ti'].numel()
+        rec['s_over_e'][k], rec['b_over_e'][k] = float(s['s_over_e']), float(s['b_over_e'])
+        rec['t0'][k], rec['tcell'][k], rec['ncell'][k] = float(s['t0']), float(s['tcell']), ncell
+        rec['cell_offset'][k], rec['photon_offset'][k] = cells, photons
+        cells += ncell
+        photons += s['ti'].numel()
+    f = lambda: torch.empty(cells, dtype=F64, device=dev)
+    i = lambda: torch.empty(cells, dtype=I64, device=dev)
+    starts, stops, exp, sexp, bexp = f(), f(), f(), f(), f()
+    dead = f() if deadtime_too else None
+    lo, hi, source = i(), i(), i()
+    ws = _workspace(_lib.lib.godot_bin_sources_workspace_bytes(len(sources), cells), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_bin_sources', rec.ctypes.data, len(sources), cells, _p(starts), _p(stops), _p(exp),
+                  _p(sexp), _p(bexp), _p(dead) if deadtime_too else 0, _p(lo), _p(hi), _p(source), _p(ws),
+                  ws.numel(), _stream(dev))
+    return starts, stops, exp, sexp, bexp, dead, lo, hi, source
 
 
 def select_cells(exp, threshold=0.0):

@@ -264,6 +264,44 @@ int godot_bin_photons(const double *ti, int64_t nph, double start0,
                       int64_t *lo, int64_t *hi, int64_t *counts,
                       godot_stream_t stream);
 
+/* Uniform cells of MANY sources in two launches: for every source what
+ * Data.get_cells(tstart, tstop, tcell, use_barycenter=False,
+ * trim_zero_exposure=False) computes for it (core.py:2064-2108) -- the edges
+ * tstart + arange(ncell + 1) * tcell, the exposures between them
+ * (Data.get_exposure(edges, cumulative=False), core.py:1806-1841) and the
+ * photon range of every cell (core.py:2097-2099) -- written side by side into
+ * arrays that hold the cells of all sources.  A loop over a thousand sky
+ * positions (the reference calls get_cells once per source) is bound by launch
+ * overhead when every source costs a handful of launches; here the launch count
+ * does not depend on the number of sources.
+ * `sources` is a HOST array of nsrc descriptors (copied to the workspace by the
+ * call; reusable as soon as it returns); the pointers inside are device
+ * pointers.  Outputs (device, total_cells entries; starts, stops, out_dead and
+ * source may be NULL): cell c of source k is entry cell_offset + c; lo/hi are
+ * indices into the source's own ti plus photon_offset (so that they index the
+ * concatenation of all photon lists when photon_offset is the number of photons
+ * before the source); source[...] = k.  The cells of consecutive descriptors
+ * must not overlap (cell_offset ascending).  Same bits as the per-source calls
+ * godot_exposure_at + godot_bin_photons on the same edges.
+ * workspace: godot_bin_sources_workspace_bytes(nsrc, total_cells).              */
+typedef struct godot_source_cells {
+    const double *tstart, *tstop, *exposure, *livetime; /* spacecraft rows [n_ft2]          */
+    const double *sexposure, *bexposure; /* rescaled per-row exposures (both) or NULL (both) */
+    const void *table;       /* godot_exposure_table (or _rows) of those rows                */
+    const double *ti;        /* time-sorted photon times [nph]                               */
+    int64_t n_ft2, nph;
+    double s_over_e, b_over_e; /* as for godot_exposure_at; unused with sexposure/bexposure  */
+    double t0, tcell;        /* edge i = i * tcell + t0, i = 0 .. ncell                      */
+    int64_t ncell;
+    int64_t cell_offset, photon_offset;
+} godot_source_cells;
+size_t godot_bin_sources_workspace_bytes(int64_t nsrc, int64_t total_cells);
+int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc, int64_t total_cells,
+                      double *starts, double *stops, double *out_exp, double *out_sexp,
+                      double *out_bexp, double *out_dead, int64_t *lo, int64_t *hi,
+                      int64_t *source, void *workspace, size_t workspace_bytes,
+                      godot_stream_t stream);
+
 /* The per-photon sums behind the reference's small per-cell functions:
  * log_full_likelihood (core.py:427-438), fmin_tnc_func (440-460), f1/f2/f3
  * (479-507), nr (509-524), halley (526-542), f1_profile (483-497) and

@@ -219,3 +219,113 @@ def test_gather_columns_is_the_per_column_gather():
         assert torch.equal(o.view(torch.int64), c[idx].view(torch.int64))
     empty = ops.gather_columns(cols[:3], idx[:0])
     assert all(e.numel() == 0 for e in empty)
+
+
+def _ragged_sources():
+    """Sources that differ in everything a descriptor carries: photon count, the span of the
+    exposure table, brightness; one of them with a single photon."""
+    from godot_amd import core, synth
+    out = []
+    for k, (nph, years) in enumerate(((30_000, 0.30), (1, 0.05), (70_000, 0.50), (5_000, 0.11), (40_000, 0.50))):
+        s = synth.synth(nph, years=years, seed=400 + k)
+        d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=DEV)
+        d.S, d.B = s['S'] * (1.0 + 0.2 * k), s['B']
+        out.append((s, d))
+    return out
+
+
+@pytest.mark.parametrize('span', [(None, None), ('inner', 'inner')])
+@pytest.mark.parametrize('tcell', [600., 86400., 3e7])
+def test_cells_of_many_sources_in_one_call_equal_the_per_source_calls(tcell, span):
+    """godot_bin_sources writes, for every source, the bits that godot_exposure_at and
+    godot_bin_photons give on that source's own edges: cell lengths from many cells a source
+    to one cell that is longer than the table (core.py:2064-2068), the whole table and an
+    inner span (the clipping of core.py:2040-2057 differs from source to source), with and
+    without the trimming of empty cells; and the first source against the oracle."""
+    from godot_amd import core
+    srcs = _ragged_sources()
+    datas = [d for _, d in srcs]
+    t0 = max(d._t0 for d in datas) + 1234.5 if span[0] else None
+    t1 = min(d._t1 for d in datas[2:]) - 777.25 if span[1] else None    # past the end of the short tables
+    for trim in (True, False):
+        one = core.get_cells_batch(datas, tstart=t0, tstop=t1, tcell=tcell, trim_zero_exposure=trim)
+        each = core.get_cells_batch(datas, tstart=t0, tstop=t1, tcell=tcell, trim_zero_exposure=trim,
+                                    per_source_calls=True)
+        assert np.array_equal(one.cell_offsets, each.cell_offsets)
+        assert torch.equal(one.source, each.source)
+        for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp', 'we', 'ti'):
+            a, b = getattr(one.cells, nm), getattr(each.cells, nm)
+            assert a.shape == b.shape and torch.equal(a.view(torch.int64), b.view(torch.int64)), nm
+    if span[0] is None:
+        s = srcs[0][0]
+        d = datas[0]
+        b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], d.S, d.B, d.E,
+                          tcell=tcell)
+        one = core.get_cells_batch(datas, tcell=tcell)
+        c0, c1 = int(one.cell_offsets[0]), int(one.cell_offsets[1])
+        assert c1 - c0 == len(b['counts'])
+        assert np.array_equal(_n(one.cells.hi - one.cells.lo)[c0:c1], b['counts'])
+        assert_same(_n(one.cells.starts)[c0:c1], b['starts'], "b['starts']")
+        assert_same(_n(one.cells.sexp)[c0:c1], b['sexp'], "b['sexp']")
+
+
+def test_bin_sources_with_dead_time_and_rejected_descriptors():
+    """The dead time of every cell equals Data.get_exposure(edges, cumulative=False)'s; a
+    descriptor table whose cells overlap, a non-positive cell length and a short workspace
+    are refused before anything is launched."""
+    import ctypes
+    from godot_amd import ops, _lib
+    srcs = _ragged_sources()[:3]
+    desc = []
+    for _, d in srcs:
+        t0, t1, tc, nc = d._uniform_cells(None, None, 7200., True)
+        desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
+                         table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
+                         t0=t0, tcell=tc, ncell=nc))
+    starts, stops, exp, sexp, bexp, dead, lo, hi, source = ops.bin_sources(desc, deadtime_too=True)
+    c = p = 0
+    for k, (_, d) in enumerate(srcs):
+        n = desc[k]['ncell']
+        edges = torch.arange(n + 1, dtype=torch.float64, device=DEV) * desc[k]['tcell'] + desc[k]['t0']
+        ref = d.get_exposure(edges, deadtime_too=True, cumulative=False)
+        for got, want in zip((exp, sexp, bexp, dead), ref):
+            assert torch.equal(got[c:c + n].view(torch.int64), want.view(torch.int64))
+        assert torch.equal(starts[c:c + n], edges[:-1]) and torch.equal(stops[c:c + n], edges[1:])
+        rl, rh, _ = ops.bin_photons(d.ti, desc[k]['t0'], edges[1:].contiguous())
+        assert torch.equal(lo[c:c + n], rl + p) and torch.equal(hi[c:c + n], rh + p)
+        assert bool((source[c:c + n] == k).all())
+        c += n
+        p += d.ti.numel()
+    # the C ABI refuses what its kernels could not index
+    rec = np.zeros(2, dtype=ops.SOURCE_CELLS)
+    for k in range(2):
+        d = srcs[k][1]
+        for nm, t in (('tstart', d.TSTART), ('tstop', d.TSTOP), ('exposure', d.exposure), ('livetime', d.LIVETIME),
+                      ('table', d._plain_exposure_table()), ('ti', d.ti)):
+            rec[nm][k] = t.data_ptr()
+        rec['n_ft2'][k], rec['nph'][k] = d.TSTART.numel(), d.ti.numel()
+        rec['t0'][k], rec['tcell'][k], rec['ncell'][k] = d._t0, 7200., 10
+    rec['cell_offset'][:] = [0, 10]
+    out = [torch.empty(20, dtype=torch.float64, device=DEV) for _ in range(3)]
+    idx = [torch.empty(20, dtype=torch.int64, device=DEV) for _ in range(2)]
+    nws = _lib.lib.godot_bin_sources_workspace_bytes(2, 20)
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+
+    def call(r, total=20, wbytes=nws):
+        return _lib.lib.godot_bin_sources(r.ctypes.data, 2, total, 0, 0, out[0].data_ptr(), out[1].data_ptr(),
+                                          out[2].data_ptr(), 0, idx[0].data_ptr(), idx[1].data_ptr(), 0,
+                                          ws.data_ptr(), wbytes, 0)
+    assert call(rec) == 0
+    torch.cuda.synchronize()
+    bad = rec.copy()
+    bad['cell_offset'][1] = 5                      # overlaps the cells of source 0
+    assert call(bad) != 0 and 'overlap' in _lib.last_error()
+    assert call(rec, total=19) != 0                # the last source passes total_cells
+    bad = rec.copy()
+    bad['tcell'][0] = 0.0
+    assert call(bad) != 0 and 'cell length' in _lib.last_error()
+    bad = rec.copy()
+    bad['table'][1] = 0
+    assert call(bad) != 0 and 'null pointer' in _lib.last_error()
+    assert call(rec, wbytes=nws - 1) != 0 and 'workspace' in _lib.last_error()
+    torch.cuda.synchronize()
