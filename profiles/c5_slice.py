@@ -1,0 +1,35 @@
+"""A slice of the multi-source job: 256 sources x 1e6 photons (16 distinct photon lists, each
+used by 16 sources with its own brightness), daily cells: binning, fit, profile grid."""
+import time, torch, numpy as np
+from godot_amd import core, ops, synth
+dev = torch.device('cuda:0')
+raw = [synth.synth(1_000_000, years=10.0, seed=1000 + k) for k in range(16)]
+srcs = []
+for j in range(16):
+    for k, ss in enumerate(raw):
+        d = core.Data(ss['ti'], ss['we'], ss['TSTART'], ss['TSTOP'], ss['LIVETIME'], ss['exposure'], device=dev)
+        d.S = ss['S'] * (1.0 + 0.05 * j)
+        srcs.append(d)
+for d in srcs:
+    d._plain_exposure_table()
+torch.cuda.synchronize()
+print('sources', len(srcs), flush=True)
+
+def timed(f, n=3):
+    f()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3, r
+
+ms_b, batch = timed(lambda: core.get_cells_batch(srcs, tcell=86400.))
+cr = batch.cells.ranges()
+ms_f, _ = timed(lambda: ops.cell_fit(cr))
+ms_g, _ = timed(lambda: ops.cell_logpdf(cr, dlogl=30, npt=200))
+print('256 sources x 1e6 photons, %d daily cells: binning %.2f ms, fit %.3f ms, 200-point grid %.2f ms' %
+      (cr.ncell, ms_b, ms_f, ms_g), flush=True)
+print('sources/s binning+fit: %.3g' % (len(srcs) / ((ms_b + ms_f) * 1e-3)), flush=True)
