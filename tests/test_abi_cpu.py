@@ -159,3 +159,31 @@ def test_every_entry_point_rejects_null_pointers_without_a_gpu():
             if fill == 1:
                 assert rc < 0, (name, 'accepted null pointers for one element')
     assert ncalls >= 120
+
+
+def test_source_descriptor_layout_is_the_headers(tmp_path):
+    """ops.SOURCE_CELLS, the numpy record the Python layer fills, has the size and the field
+    offsets that a C compiler gives godot_source_cells of include/godot_hip.h."""
+    import shutil
+    import subprocess
+    from godot_amd import ops
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    names = list(ops.SOURCE_CELLS.names)
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "godot_hip.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(godot_source_cells));\n'
+                   + ''.join('printf("%%zu\\n", offsetof(godot_source_cells, %s));\n' % n for n in names)
+                   + 'return 0;}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.dirname(HEADER), str(src), '-o', str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ops.SOURCE_CELLS.itemsize
+    assert out[1:] == [ops.SOURCE_CELLS.fields[n][1] for n in names]
+    # and the call refuses a table it cannot index before any device work
+    from godot_amd import _lib
+    rec = np.zeros(1, dtype=ops.SOURCE_CELLS)
+    rec['n_ft2'], rec['ncell'], rec['tcell'] = 10, 5, 1.0
+    assert _lib.lib.godot_bin_sources(rec.ctypes.data, 1, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert 'null pointer' in _lib.last_error()
+    assert _lib.lib.godot_bin_sources_workspace_bytes(3, 100) >= 3 * ops.SOURCE_CELLS.itemsize + 32 * 103
