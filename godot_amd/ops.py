@@ -391,39 +391,47 @@ def bin_sources(sources, deadtime_too=False):
     if not sources:
         raise ValueError('no sources')
     dev = sources[0]['ti'].device
-    rec = np.zeros(len(sources), dtype=SOURCE_CELLS)
+    col = {n: [] for n in SOURCE_CELLS.names}       # filled column by column: one numpy call a field
     cells = photons = 0
     for k, s in enumerate(sources):
         n_ft2 = s['tstart'].numel()
-        for nm in ('tstart', 'tstop', 'exposure', 'livetime'):
-            _dev_check(s[nm], F64, nm)
-            if s[nm].numel() != n_ft2:
-                raise ValueError('source %d: the exposure table columns must have equal lengths' % k)
-            rec[nm][k] = s[nm].data_ptr()
-        if (s.get('sexposure') is None) != (s.get('bexposure') is None):
+        for nm in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure'):
+            t = s.get(nm)
+            if t is None:
+                if nm in ('sexposure', 'bexposure'):
+                    col[nm].append(0)
+                    continue
+                raise ValueError('source %d: no %s' % (k, nm))
+            _dev_check(t, F64, nm)
+            if t.numel() != n_ft2 or t.device != dev:
+                raise ValueError('source %d: the exposure table columns must have equal lengths and live on '
+                                 'the device of the batch' % k)
+            col[nm].append(t.data_ptr())
+        if (col['sexposure'][-1] == 0) != (col['bexposure'][-1] == 0):
             raise ValueError('source %d: sexposure and bexposure come together' % k)
-        for nm in ('sexposure', 'bexposure'):
-            if s.get(nm) is not None:
-                _dev_check(s[nm], F64, nm)
-                if s[nm].numel() != n_ft2:
-                    raise ValueError('source %d: the exposure table columns must have equal lengths' % k)
-                rec[nm][k] = s[nm].data_ptr()
-        _dev_check(s['ti'], F64, 'ti')
-        if s['ti'].device != dev or s['tstart'].device != dev:
+        ti, table = s['ti'], s['table']
+        _dev_check(ti, F64, 'ti')
+        if ti.device != dev:
             raise ValueError('source %d: all sources of a batch live on one device' % k)
-        if s['table'].device != dev or s['table'].numel() < _lib.lib.godot_exposure_table_bytes(n_ft2):
+        if table.device != dev or table.numel() < _lib.lib.godot_exposure_table_bytes(n_ft2):
             raise ValueError('source %d: the table does not belong to these %d rows' % (k, n_ft2))
         ncell = int(s['ncell'])
         if ncell < 0 or not float(s['tcell']) > 0:
             raise ValueError('source %d: needs ncell >= 0 and tcell > 0' % k)
-        rec['table'][k] = s['table'].data_ptr()
-        rec['ti'][k] = s['ti'].data_ptr()
-        rec['n_ft2'][k], rec['nph'][k] = n_ft2, s['ti'].numel()
-        rec['s_over_e'][k], rec['b_over_e'][k] = float(s['s_over_e']), float(s['b_over_e'])
-        rec['t0'][k], rec['tcell'][k], rec['ncell'][k] = float(s['t0']), float(s['tcell']), ncell
-        rec['cell_offset'][k], rec['photon_offset'][k] = cells, photons
+        col['table'].append(table.data_ptr())
+        col['ti'].append(ti.data_ptr())
+        col['n_ft2'].append(n_ft2)
+        col['nph'].append(ti.numel())
+        for nm in ('s_over_e', 'b_over_e', 't0', 'tcell'):
+            col[nm].append(float(s[nm]))
+        col['ncell'].append(ncell)
+        col['cell_offset'].append(cells)
+        col['photon_offset'].append(photons)
         cells += ncell
-        photons += s['ti'].numel()
+        photons += ti.numel()
+    rec = np.zeros(len(sources), dtype=SOURCE_CELLS)
+    for nm in SOURCE_CELLS.names:
+        rec[nm] = col[nm]
     f = lambda: torch.empty(cells, dtype=F64, device=dev)
     i = lambda: torch.empty(cells, dtype=I64, device=dev)
     starts, stops, exp, sexp, bexp = f(), f(), f(), f(), f()
