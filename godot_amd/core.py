@@ -1436,6 +1436,41 @@ class SourceBatch(object):
         return [rows[int(o[k]):int(o[k + 1])] for k in range(len(o) - 1)]
 
 
+def _joined(parts):
+    """The arrays of `parts` one after another as ONE tensor: a view when they already lie
+    like that in one allocation (pack_sources puts them there), else a copy."""
+    full = [t for t in parts if t.numel() > 0]
+    if not full:
+        return torch.cat(parts)
+    first = full[0]
+    store = first.untyped_storage()
+    at = first.data_ptr()
+    for t in full:
+        if not t.is_contiguous() or t.dtype != first.dtype or t.data_ptr() != at \
+                or t.untyped_storage().data_ptr() != store.data_ptr():
+            return torch.cat(parts)
+        at += t.numel() * t.element_size()
+    total = sum(t.numel() for t in full)
+    return torch.empty(0, dtype=first.dtype, device=first.device).set_(store, first.storage_offset(), (total,))
+
+
+def pack_sources(sources):
+    """Move the photon lists of the Data objects into one allocation, source after source
+    (every object's ti and we become views into it; values and order unchanged), so that
+    get_cells_batch hands the kernels the concatenated lists without copying them at every
+    call: 16 bytes a photon, a gigabyte for 64 sources of 10^6 photons.  Returns `sources`."""
+    for name in ('ti', 'we'):
+        parts = [getattr(d, name) for d in sources]
+        if not all(t.is_contiguous() for t in parts):
+            parts = [t.contiguous() for t in parts]
+        whole = torch.cat(parts)
+        at = 0
+        for d, t in zip(sources, parts):
+            setattr(d, name, whole[at:at + t.numel()])
+            at += t.numel()
+    return sources
+
+
 def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
                     per_source_calls=False):
     """Data.get_cells(tstart, tstop, tcell, use_barycenter=False) for every Data object of
@@ -1471,7 +1506,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
                              t0=t0, tcell=tc, ncell=nc))
         starts, stops, _, sexp, bexp, _, lo, hi, source = ops.bin_sources(desc)
         ncl = np.array([s['ncell'] for s in desc], dtype=np.int64)
-    we, ti = torch.cat([d.we for d in sources]), torch.cat([d.ti for d in sources])
+    we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
     if trim_zero_exposure:
         # a cell has exposure exactly when it has source exposure (sexp = S / E * exp, S > 0)
         keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch

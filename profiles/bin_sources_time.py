@@ -20,6 +20,17 @@ for n in (16, 64):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         print('sources %d per_source_calls=%s: %.3f ms (min of 5), cells %d' % (n, per, min(ts) * 1e3, len(b.cells.lo)), flush=True)
+core.pack_sources(srcs)
+for n in (16, 64):
+    core.get_cells_batch(srcs[:n], tcell=86400.)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        b = core.get_cells_batch(srcs[:n], tcell=86400.)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    print('sources %d packed (core.pack_sources: the photon lists in one allocation): %.3f ms (min of 5)' % (n, min(ts) * 1e3), flush=True)
 # without the concatenation of the photon lists (what a caller that keeps them concatenated pays)
 desc = []
 for d in srcs:

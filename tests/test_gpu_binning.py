@@ -329,3 +329,31 @@ def test_bin_sources_with_dead_time_and_rejected_descriptors():
     assert call(bad) != 0 and 'null pointer' in _lib.last_error()
     assert call(rec, wbytes=nws - 1) != 0 and 'workspace' in _lib.last_error()
     torch.cuda.synchronize()
+
+
+def test_packed_sources_are_binned_without_copying_their_photons():
+    """core.pack_sources moves the photon lists into one allocation; the batch then hands out
+    a view of it (no copy of 16 bytes a photon per call) and every array of the batch equals
+    the unpacked batch's; a source whose list is replaced afterwards falls back to the copy."""
+    from godot_amd import core
+    datas = [d for _, d in _ragged_sources()]
+    ref = core.get_cells_batch(datas, tcell=3600.)
+    before = [(d.ti.clone(), d.we.clone()) for d in datas]
+    assert core.pack_sources(datas) is datas
+    for d, (ti, we) in zip(datas, before):
+        assert torch.equal(d.ti, ti) and torch.equal(d.we, we)
+    got = core.get_cells_batch(datas, tcell=3600.)
+    assert got.cells.we.data_ptr() == datas[0].we.data_ptr()
+    assert got.cells.ti.data_ptr() == datas[0].ti.data_ptr()
+    assert np.array_equal(got.cell_offsets, ref.cell_offsets) and torch.equal(got.source, ref.source)
+    for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp', 'we', 'ti'):
+        a, b = getattr(got.cells, nm), getattr(ref.cells, nm)
+        assert a.shape == b.shape and torch.equal(a.view(torch.int64), b.view(torch.int64)), nm
+    # single sources still work on their views
+    one = datas[2].get_cells(tcell=3600., use_barycenter=False, quiet=True)
+    c0, c1 = int(ref.cell_offsets[2]), int(ref.cell_offsets[3])
+    assert torch.equal(one.sexp, ref.cells.sexp[c0:c1]) and torch.equal(one.hi - one.lo, (ref.cells.hi - ref.cells.lo)[c0:c1])
+    datas[1].we = datas[1].we.clone()
+    again = core.get_cells_batch(datas, tcell=3600.)
+    assert again.cells.we.data_ptr() != datas[0].we.data_ptr()
+    assert torch.equal(again.cells.we, ref.cells.we) and torch.equal(again.cells.lo, ref.cells.lo)
