@@ -558,7 +558,8 @@ def run_rank(args):
         torch.cuda.empty_cache()
 
         # multi-source batch (the C5 shape at 16 of its 1000 sources): C1 lists (1e6 photons, daily
-        # cells) of 16 sources binned into one batch (one wait for the device) and fitted by one launch
+        # cells) of 16 sources binned into one batch (two launches for all sources, one wait for the
+        # device) and fitted by one launch
         nsrc = 16
         srcs = []
         for k in range(nsrc):
@@ -567,6 +568,7 @@ def run_rank(args):
                                   device=dev))
         for d_ in srcs:
             d_.get_cells(tcell=86400., use_barycenter=False, quiet=True)      # exposure tables built
+        core.pack_sources(srcs)                    # photon lists in one allocation: batches are views
         torch.cuda.synchronize()
         t0f = time.perf_counter()
         core.get_cells_batch(srcs, tcell=86400.)       # first call: code objects load, the allocator grows
