@@ -357,3 +357,32 @@ def test_packed_sources_are_binned_without_copying_their_photons():
     again = core.get_cells_batch(datas, tcell=3600.)
     assert again.cells.we.data_ptr() != datas[0].we.data_ptr()
     assert torch.equal(again.cells.we, ref.cells.we) and torch.equal(again.cells.lo, ref.cells.lo)
+
+
+def test_bin_sources_beyond_one_grid_of_sources():
+    """More sources than a launch grid has rows (65 535): the call makes a second pair of
+    launches for the rest, and every source -- here 66 000 descriptors of two photon lists in
+    turn -- gets the cells of its own list, its photon indices shifted by what lies before it."""
+    from godot_amd import ops
+    pair = [d for _, d in _ragged_sources()[:3:2]]
+    desc = []
+    for d in pair:
+        t0, t1, tc, nc = d._uniform_cells(None, d._t0 + 5 * 86400. + 1.0, 86400., True)
+        assert nc == 5
+        desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
+                         table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
+                         t0=t0, tcell=tc, ncell=nc))
+    ref = ops.bin_sources(desc)
+    nsrc = 66_000
+    out = ops.bin_sources([desc[k & 1] for k in range(nsrc)])
+    n0, n1 = pair[0].ti.numel(), pair[1].ti.numel()
+    k = torch.arange(nsrc, device=DEV)
+    before = (k + 1) // 2 * n0 + k // 2 * n1                       # photons ahead of source k
+    for i in (0, 1, 2, 3, 4):                                      # starts, stops, exp, sexp, bexp
+        got = out[i].view(nsrc // 2, 10)
+        assert torch.equal(got.view(torch.int64), ref[i].view(torch.int64).expand(nsrc // 2, 10))
+    for i in (6, 7):                                               # lo, hi
+        own = torch.cat([ref[i][:5], ref[i][5:] - n0])             # indices into each list alone
+        got = out[i].view(nsrc, 5) - before[:, None]
+        assert torch.equal(got.view(nsrc // 2, 10), own.expand(nsrc // 2, 10))
+    assert torch.equal(out[8].view(nsrc, 5), k[:, None].expand(nsrc, 5))
