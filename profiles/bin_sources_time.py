@@ -47,3 +47,18 @@ for _ in range(5):
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 print('ops.bin_sources of 64 sources alone: %.3f ms' % (min(ts) * 1e3), flush=True)
+# the input of a power spectrum per source: 300-s bins (1.05e6 a source)
+for n in (16,):
+    for name, f in (('per source', lambda: [d.get_cells(tcell=300., time_series_only=True, use_barycenter=False,
+                                                         quiet=True) for d in srcs[:n]]),
+                    ('batch', lambda: core.get_timeseries_batch(srcs[:n], tcell=300.))):
+        f()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r = f()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        print('time series of %d sources in 300-s bins, %s: %.3f ms (min of 5), bins %d' %
+              (n, name, min(ts) * 1e3, sum(len(x.exp) for x in r)), flush=True)

@@ -386,3 +386,35 @@ def test_bin_sources_beyond_one_grid_of_sources():
         got = out[i].view(nsrc, 5) - before[:, None]
         assert torch.equal(got.view(nsrc // 2, 10), own.expand(nsrc // 2, 10))
     assert torch.equal(out[8].view(nsrc, 5), k[:, None].expand(nsrc, 5))
+
+
+@pytest.mark.parametrize('trim', [True, False])
+def test_time_series_of_many_sources_equal_the_per_source_calls(trim):
+    """core.get_timeseries_batch gives every source the CellTimeSeries of its own
+    get_cells(..., time_series_only=True): edges, exposures, dead time and counts bit for bit,
+    the weight moments to the last bits (their sums may be formed in another order when the
+    cells of all sources share a launch), and the power spectrum of a source follows."""
+    from godot_amd import core
+    datas = [d for _, d in _ragged_sources()]
+    t1 = min(d._t1 for d in datas[2:]) - 777.25
+    got = core.get_timeseries_batch(datas, tstop=t1, tcell=300., trim_zero_exposure=trim)
+    assert len(got) == len(datas)
+    for d, ts in zip(datas, got):
+        ref = d.get_cells(tstop=t1, tcell=300., time_series_only=True, use_barycenter=False,
+                          trim_zero_exposure=trim, quiet=True)
+        assert ts.timesys == ref.timesys and ts.minimum_exposure == ref.minimum_exposure
+        for nm in ('starts', 'stops', 'exp', 'sexp', 'bexp', 'deadtime', 'counts'):
+            a, b = getattr(ts, nm), getattr(ref, nm)
+            assert a.shape == b.shape and torch.equal(a.view(torch.int64), b.view(torch.int64)), nm
+        for nm in ('weights', 'weights2'):
+            a, b = _n(getattr(ts, nm)), _n(getattr(ref, nm))
+            assert a.shape == b.shape and np.all(np.abs(a - b) <= 4e-16 * np.maximum(np.abs(b), 1.0)), nm
+    f, p0, p1, pb = core.power_spectrum_fft(got[2])
+    ref = datas[2].get_cells(tstop=t1, tcell=300., time_series_only=True, use_barycenter=False,
+                             trim_zero_exposure=trim, quiet=True)
+    rf, r0, r1, rb = core.power_spectrum_fft(ref)
+    assert np.array_equal(f, rf)
+    for a, b in ((p0, r0), (p1, r1), (pb, rb)):
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin)
+        assert np.all(np.abs(a[fin] - b[fin]) <= 1e-9 * np.maximum(np.abs(b[fin]), 1e-3 * np.abs(b[fin]).max()))
