@@ -1436,6 +1436,13 @@ class SourceBatch(object):
         return [rows[int(o[k]):int(o[k + 1])] for k in range(len(o) - 1)]
 
 
+def _kept_per_source(keep, ncl):
+    """How many of every source's cells a selection kept: `keep` holds the ascending indices
+    of the kept cells, source k owns the ncl[k] cells after those of the sources before it."""
+    edges = torch.from_numpy(np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64)).to(keep.device)
+    return np.diff(torch.searchsorted(keep, edges).cpu().numpy())
+
+
 def _joined(parts):
     """The arrays of `parts` one after another as ONE tensor: a view when they already lie
     like that in one allocation (pack_sources puts them there), else a copy."""
@@ -1512,7 +1519,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch
         lo, hi, starts, stops, sexp, bexp, source = ops.gather_columns(
             [c.contiguous() for c in (lo, hi, starts, stops, sexp, bexp, source)], keep)
-        ncl = torch.bincount(source, minlength=len(sources)).cpu().numpy()
+        ncl = _kept_per_source(keep, ncl)
     cells = CellBatch(we, ti, lo.contiguous(), hi.contiguous(), starts, stops, sexp, bexp)
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
 
@@ -1545,10 +1552,9 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
     ncl = np.array([s['ncell'] for s in desc], dtype=np.int64)
     cols = [starts, stops, exp, sexp, bexp, counts, w1, w2, dead]
     if trim_zero_exposure:
-        kept = torch.zeros(len(sources), dtype=I64, device=exp.device).index_add_(0, source, (exp > 0).to(I64))
         keep = ops.select_cells(exp, 0.0)                      # the one wait of the batch
         cols = ops.gather_columns([c.contiguous() for c in cols], keep)
-        ncl = kept.cpu().numpy()
+        ncl = _kept_per_source(keep, ncl)
     else:
         # what the constructor does to cells without exposure (minimum_exposure = 0), once for all
         mask = ~(cols[2] > 0)
