@@ -1306,7 +1306,8 @@ extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc
                       GODOT_E_INVALID, "godot_bin_sources: source %lld: null pointer", (long long)k);
         GODOT_REQUIRE((s.sexposure == nullptr) == (s.bexposure == nullptr), GODOT_E_INVALID,
                       "godot_bin_sources: source %lld: one rescaled exposure without the other", (long long)k);
-        GODOT_REQUIRE(s.tcell > 0, GODOT_E_INVALID, "godot_bin_sources: source %lld: cell length must be positive",
+        GODOT_REQUIRE(s.tcell > 0 && isfinite(s.tcell) && isfinite(s.t0), GODOT_E_INVALID,
+                      "godot_bin_sources: source %lld: cell length must be positive and finite, the first edge finite",
                       (long long)k);
         GODOT_REQUIRE(s.cell_offset >= end && s.cell_offset + s.ncell <= total_cells, GODOT_E_INVALID,
                       "godot_bin_sources: source %lld: its cells [%lld, %lld) overlap the source before or pass "

@@ -325,6 +325,12 @@ def test_bin_sources_with_dead_time_and_rejected_descriptors():
     bad['tcell'][0] = 0.0
     assert call(bad) != 0 and 'cell length' in _lib.last_error()
     bad = rec.copy()
+    bad['tcell'][1] = np.inf
+    assert call(bad) != 0 and 'cell length' in _lib.last_error()
+    bad = rec.copy()
+    bad['t0'][0] = np.nan
+    assert call(bad) != 0 and 'first edge' in _lib.last_error()
+    bad = rec.copy()
     bad['table'][1] = 0
     assert call(bad) != 0 and 'null pointer' in _lib.last_error()
     assert call(rec, wbytes=nws - 1) != 0 and 'workspace' in _lib.last_error()
