@@ -7,7 +7,8 @@ S=${1:-0}
 TAG=${2:-sw$S}
 mkdir -p gpurun_out
 for s in "sweep_fit.py $S 40 100" "sweep_binning.py $S 40" "sweep_exposure.py $S 60" "sweep_spectra_blocks.py $S" "sweep_beta.py $S 40" \
-         "sweep_trigsums.py $S 40" "sweep_lightcurve.py $S 30" "sweep_timeseries.py $S 40" "sweep_profile_bkg.py $S 40"; do
+         "sweep_trigsums.py $S 40" "sweep_lightcurve.py $S 30" "sweep_timeseries.py $S 40" "sweep_profile_bkg.py $S 40" \
+         "sweep_batch.py $S 30"; do
     set -- $s
     log=gpurun_out/${TAG}_${1%.py}.log
     timeout -k 10 300 python3 -u tests/sweeps/$s > $log 2>&1
