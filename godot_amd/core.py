@@ -1493,7 +1493,12 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
     if not sources:
         raise ValueError('no sources')
     dev = sources[0].device
-    if per_source_calls or any(d.sexposure is not None for d in sources):
+    spans = None
+    if not (per_source_calls or any(d.sexposure is not None for d in sources)):
+        spans = [d._uniform_cells(tstart, tstop, tcell, quiet) for d in sources]
+        if any(not tc > 0 or nc < 1 for _, _, tc, nc in spans):
+            spans = None         # a span that ends before it begins: whatever get_cells makes of it
+    if spans is None:
         per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=False,
                            use_barycenter=False, quiet=quiet) for d in sources]
         nph = np.array([b.we.numel() for b in per], dtype=np.int64)
@@ -1506,8 +1511,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
     else:
         desc = []
-        for d in sources:
-            t0, t1, tc, nc = d._uniform_cells(tstart, tstop, tcell, quiet)
+        for d, (t0, t1, tc, nc) in zip(sources, spans):
             desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
                              table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
                              t0=t0, tcell=tc, ncell=nc))
@@ -1536,12 +1540,16 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
         raise ValueError('get_timeseries_batch needs a cell length')
     if not sources:
         raise ValueError('no sources')
-    if any(d.sexposure is not None for d in sources):
+    spans = None
+    if not any(d.sexposure is not None for d in sources):
+        spans = [d._uniform_cells(tstart, tstop, tcell, quiet) for d in sources]
+        if any(not tc > 0 or nc < 1 for _, _, tc, nc in spans):
+            spans = None         # a span that ends before it begins: whatever get_cells makes of it
+    if spans is None:
         return [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
                             time_series_only=True, use_barycenter=False, quiet=quiet) for d in sources]
     desc = []
-    for d in sources:
-        t0, t1, tc, nc = d._uniform_cells(tstart, tstop, tcell, quiet)
+    for d, (t0, t1, tc, nc) in zip(sources, spans):
         desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
                          table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
                          t0=t0, tcell=tc, ncell=nc))

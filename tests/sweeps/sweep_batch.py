@@ -31,6 +31,7 @@ def same(a, b):
 
 
 nbad = 0
+worst = 0.0
 for conf in range(nconf):
     rng = np.random.default_rng(9100 * seed0 + conf)
     made = [source(rng) for _ in range(int(rng.integers(2, 7)))]
@@ -74,10 +75,17 @@ for conf in range(nconf):
                 if not same(getattr(ts, nm), getattr(ref, nm)): what.append('ts %d %s' % (k, nm))
             for nm in ('weights', 'weights2'):
                 a, b = getattr(ts, nm).cpu().numpy(), getattr(ref, nm).cpu().numpy()
-                if a.shape != b.shape or not np.all(np.abs(a - b) <= 4e-16 * np.maximum(np.abs(b), 1.0)):
-                    what.append('ts %d %s' % (k, nm))
+                # sums of positive terms: a cell's photons may be added in another order when the
+                # cells of all sources share a launch (the kernel's shape follows the mean cell size)
+                if a.shape != b.shape:
+                    what.append('ts %d %s shape' % (k, nm))
+                elif a.size and not np.all(np.abs(a - b) <= 1e-13 * np.maximum(np.abs(b), 1.0)):
+                    what.append('ts %d %s %.3g' % (k, nm, np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))))
+                elif a.size:
+                    worst = max(worst, float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))))
     nbad += bool(what)
     print('conf %d sources %d tcell %g trim %d kw %s -> %s: %s' % (
         conf, len(datas), tcell, trim, sorted(kw), 'err %r' % oerr if oerr is not None else '%d cells' % len(one.cells.lo),
         what or 'ok'), flush=True)
+print('largest relative difference of a weight moment: %.3g' % worst)
 print('TOTAL BAD', nbad)

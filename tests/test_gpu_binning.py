@@ -414,7 +414,7 @@ def test_time_series_of_many_sources_equal_the_per_source_calls(trim):
             assert a.shape == b.shape and torch.equal(a.view(torch.int64), b.view(torch.int64)), nm
         for nm in ('weights', 'weights2'):
             a, b = _n(getattr(ts, nm)), _n(getattr(ref, nm))
-            assert a.shape == b.shape and np.all(np.abs(a - b) <= 4e-16 * np.maximum(np.abs(b), 1.0)), nm
+            assert a.shape == b.shape and np.all(np.abs(a - b) <= 1e-13 * np.maximum(np.abs(b), 1.0)), nm
     f, p0, p1, pb = core.power_spectrum_fft(got[2])
     ref = datas[2].get_cells(tstop=t1, tcell=300., time_series_only=True, use_barycenter=False,
                              trim_zero_exposure=trim, quiet=True)
@@ -424,3 +424,27 @@ def test_time_series_of_many_sources_equal_the_per_source_calls(trim):
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin)
         assert np.all(np.abs(a[fin] - b[fin]) <= 1e-9 * np.maximum(np.abs(b[fin]), 1e-3 * np.abs(b[fin]).max()))
+
+
+def test_batch_with_a_span_that_ends_before_a_source_begins():
+    """A requested span that lies past the end of one source's table leaves that source a cell
+    of no length (core.py:2064-2068 with tstop clipped below tstart): the batch then takes the
+    per-source calls, whatever they make of it, instead of refusing the descriptor."""
+    from godot_amd import core
+    datas = [d for _, d in _ragged_sources()]
+    t0 = datas[1]._t1 + 5000.0                     # beyond the 0.05-year table of source 1
+    outcome = []
+    for per in (True, False):
+        try:
+            b = core.get_cells_batch(datas, tstart=t0, tcell=86400., trim_zero_exposure=False, per_source_calls=per)
+            outcome.append((None, b))
+        except Exception as e:                     # the same failure either way, if it is one
+            outcome.append((type(e), None))
+    assert outcome[0][0] is outcome[1][0]
+    if outcome[0][0] is None:
+        a, b = outcome[0][1], outcome[1][1]
+        assert np.array_equal(a.cell_offsets, b.cell_offsets)
+        for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp'):
+            assert torch.equal(getattr(a.cells, nm).view(torch.int64), getattr(b.cells, nm).view(torch.int64)), nm
+    ts = core.get_timeseries_batch(datas, tstart=t0, tcell=86400., trim_zero_exposure=False)
+    assert len(ts) == len(datas)
