@@ -448,3 +448,36 @@ def test_batch_with_a_span_that_ends_before_a_source_begins():
             assert torch.equal(getattr(a.cells, nm).view(torch.int64), getattr(b.cells, nm).view(torch.int64)), nm
     ts = core.get_timeseries_batch(datas, tstart=t0, tcell=86400., trim_zero_exposure=False)
     assert len(ts) == len(datas)
+
+
+def test_bin_sources_with_rescaled_exposure_rows():
+    """A descriptor may carry per-row source and background exposures (what apply_scalers
+    leaves in Data.sexposure / bexposure, core.py:2282-2306) with the table built from them;
+    mixed with a plain source in one batch, each gets the bits of its own per-source call."""
+    from godot_amd import ops
+    (s0, d0), (s1, d1) = _ragged_sources()[:3:2]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    n = d0.exposure.numel()
+    sexposure = (d0.exposure * (d0.S / d0.E) * (0.5 + torch.rand(n, dtype=torch.float64, device=DEV, generator=g))).contiguous()
+    bexposure = (d0.exposure * (d0.B / d0.E) * (0.5 + torch.rand(n, dtype=torch.float64, device=DEV, generator=g))).contiguous()
+    table = ops.exposure_table_rows(d0.TSTART, d0.TSTOP, d0.exposure, sexposure, bexposure, d0.LIVETIME)
+    desc = []
+    for d, extra in ((d0, dict(sexposure=sexposure, bexposure=bexposure, table=table)),
+                     (d1, dict(table=d1._plain_exposure_table()))):
+        t0, t1, tc, nc = d._uniform_cells(None, None, 5400., True)
+        desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME, ti=d.ti,
+                         s_over_e=d.S / d.E, b_over_e=d.B / d.E, t0=t0, tcell=tc, ncell=nc, **extra))
+    out = ops.bin_sources(desc, deadtime_too=True)
+    n0, n1 = desc[0]['ncell'], desc[1]['ncell']
+    e0 = torch.arange(n0 + 1, dtype=torch.float64, device=DEV) * desc[0]['tcell'] + desc[0]['t0']
+    ref0 = ops.exposure_at_rows(d0.TSTART, d0.TSTOP, d0.exposure, sexposure, bexposure, d0.LIVETIME, table, e0,
+                                cumulative=False, deadtime_too=True)
+    e1 = torch.arange(n1 + 1, dtype=torch.float64, device=DEV) * desc[1]['tcell'] + desc[1]['t0']
+    ref1 = d1.get_exposure(e1, deadtime_too=True, cumulative=False)
+    for got, a, b in zip((out[2], out[3], out[4], out[5]), ref0, ref1):
+        assert torch.equal(got[:n0].view(torch.int64), a.view(torch.int64))
+        assert torch.equal(got[n0:].view(torch.int64), b.view(torch.int64))
+    assert not torch.equal(out[3][:n0], out[2][:n0] * (d0.S / d0.E))      # the rescaled rows were used
+    with pytest.raises(ValueError):
+        ops.bin_sources([dict(desc[0], bexposure=None)])
