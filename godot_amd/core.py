@@ -1436,6 +1436,29 @@ class SourceBatch(object):
         return [rows[int(o[k]):int(o[k + 1])] for k in range(len(o) - 1)]
 
 
+def build_exposure_tables(sources, nstream=4):
+    """The running-sum tables of many Data objects (what the first get_exposure / get_cells of
+    each would build), issued over `nstream` HIP streams.  The exact running sums are a chain of
+    six launches per source, two of them a handful of workgroups that walk the table in order
+    while the rest of the chip idles; tables of different sources do not depend on one another,
+    so the walks of some overlap the streaming launches of others.  Same tables, bit for bit,
+    as one after another.  Returns `sources`."""
+    todo = [d for d in sources if d._exposure_table is None]
+    if not todo:
+        return sources
+    dev = todo[0].device
+    here = torch.cuda.current_stream(dev)
+    streams = [torch.cuda.Stream(dev) for _ in range(max(1, min(int(nstream), len(todo))))]
+    for st in streams:
+        st.wait_stream(here)
+    for k, d in enumerate(todo):
+        with torch.cuda.stream(streams[k % len(streams)]):
+            d._plain_exposure_table().record_stream(here)
+    for st in streams:
+        here.wait_stream(st)
+    return sources
+
+
 def _kept_per_source(keep, ncl):
     """How many of every source's cells a selection kept: `keep` holds the ascending indices
     of the kept cells, source k owns the ncl[k] cells after those of the sources before it."""

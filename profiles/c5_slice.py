@@ -10,8 +10,18 @@ for j in range(16):
         d = core.Data(ss['ti'], ss['we'], ss['TSTART'], ss['TSTOP'], ss['LIVETIME'], ss['exposure'], device=dev)
         d.S = ss['S'] * (1.0 + 0.05 * j)
         srcs.append(d)
-for d in srcs:
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for d in srcs[:32]:
     d._plain_exposure_table()
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+core.build_exposure_tables(srcs[32:64], nstream=4)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('exposure tables of 32 sources (8.3e6 rows each): one after another %.1f ms, over four streams %.1f ms' %
+      ((t1 - t0) * 1e3, (t2 - t1) * 1e3), flush=True)
+core.build_exposure_tables(srcs, nstream=4)
 torch.cuda.synchronize()
 print('sources', len(srcs), flush=True)
 

@@ -481,3 +481,34 @@ def test_bin_sources_with_rescaled_exposure_rows():
     assert not torch.equal(out[3][:n0], out[2][:n0] * (d0.S / d0.E))      # the rescaled rows were used
     with pytest.raises(ValueError):
         ops.bin_sources([dict(desc[0], bexposure=None)])
+
+
+def test_exposure_tables_built_on_several_streams_are_the_same_tables():
+    """core.build_exposure_tables issues the table builds of many sources over several streams;
+    every table equals, byte for byte in the part queries read, the one built alone, and the
+    cells binned from them are the same."""
+    from godot_amd import core, ops
+    datas = [d for _, d in _ragged_sources()]
+    alone = []
+    for d in datas:
+        t = ops.exposure_table(d.TSTART, d.TSTOP, d.exposure, d.LIVETIME, d.S / d.E, d.B / d.E)
+        alone.append(t.clone())
+    assert all(d._exposure_table is None for d in datas)
+    assert core.build_exposure_tables(datas, nstream=3) is datas
+    torch.cuda.synchronize()
+    for d, t in zip(datas, alone):
+        n = d.TSTART.numel()
+        used = 80 * n                      # 32 bytes of running sums and 48 bytes of row a table row
+        assert d._exposure_table is not None
+        got = d._exposure_table
+        assert got.numel() == t.numel()
+        sums = -(-32 * n // 256) * 256     # the rows follow the sums on a 256-byte boundary
+        assert torch.equal(got[:32 * n], t[:32 * n])
+        assert torch.equal(got[sums:sums + 48 * n], t[sums:sums + 48 * n])
+        assert used <= got.numel()
+    core.build_exposure_tables(datas)      # nothing left to do
+    a = core.get_cells_batch(datas, tcell=3600.)
+    fresh = [d for _, d in _ragged_sources()]
+    b = core.get_cells_batch(fresh, tcell=3600.)
+    for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp'):
+        assert torch.equal(getattr(a.cells, nm).view(torch.int64), getattr(b.cells, nm).view(torch.int64)), nm
