@@ -1533,6 +1533,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         starts, stops, sexp, bexp = cat('starts'), cat('stops'), cat('sexp'), cat('bexp')
         source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
     else:
+        build_exposure_tables(sources)              # those still to build: over several streams
         desc = []
         for d, (t0, t1, tc, nc) in zip(sources, spans):
             desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
@@ -1571,6 +1572,7 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
     if spans is None:
         return [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
                             time_series_only=True, use_barycenter=False, quiet=quiet) for d in sources]
+    build_exposure_tables(sources)
     desc = []
     for d, (t0, t1, tc, nc) in zip(sources, spans):
         desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
