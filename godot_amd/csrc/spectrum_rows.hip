@@ -7,7 +7,7 @@
 //   X[m + R p] = sum_b W_B^(b p) * [ W_L^(b m) * C_b[m] ],     C_b[m] = sum_r x[B r + b] W_R^(r m)
 //
 // Pass A (columns_kernel) transforms every column: the padding leaves only the first rows
-// non-zero, r = r_lo + R1 r_hi with r_hi < nhi (nhi = 2 .. 4 for the default padding), so
+// non-zero, r = r_lo + R1 r_hi with r_hi < nhi (nhi = 2 .. 7 for the default padding), so
 // the sixteen values m mod 16 = c come from nhi samples each,
 //   E_c[r_lo] = W_R^(r_lo c) sum_(r_hi < nhi) x[B (r_lo + R1 r_hi) + b] W_16^(r_hi c),
 // and C_b[c + 16 m_hi] is the R1-point transform of E_c.  The column is real, so
@@ -16,12 +16,13 @@
 // of the upper half of its output; the classes 0 and 8 are their own partners.  Only the
 // rows m <= R/2 are kept: V[m][b] = W_L^(b m) C_b[m], (R/2 + 1) * B complex numbers, the same
 // volume as the packed half-length transform.  A workgroup takes NC adjacent columns and
-// one class; the samples it reads are shared with 9 * (16 / NC) neighbours, which are
-// placed on the same XCD one after the other so that the reads come from that XCD's L2.
+// one class, a wavefront per column (no workgroup barrier inside a transform); the samples
+// were regrouped column by column beforehand (gather_kernel), and the nine workgroups that
+// read the same columns follow one another on one XCD, whose L2 serves eight of the reads.
 //
-// Pass B (rows_kernel) transforms rows: row m of V is contiguous, its B-point transform
-// is X[m + R p], and because x is real X[(R - m) + R p'] = conj of the same row's output
-// B - 1 - p'.  The estimators need the bins k <= l/4 only: outputs p < B/4 and
+// Pass B (rows2048_kernel, rows_kernel) transforms rows: row m of V is contiguous, its
+// B-point transform is X[m + R p], and because x is real X[(R - m) + R p'] = conj of the same
+// row's output B - 1 - p'.  The estimators need the bins k <= l/4 only: outputs p < B/4 and
 // p >= 3B/4 of a row.  The three second-moment series enter through the real parts of the
 // even bins of their length-l transforms, i.e. through length-l/2 transforms with the same
 // R rows of half the length, whose row m holds the same bins k.  A workgroup takes NR
@@ -32,14 +33,15 @@
 
 using namespace godot_spectrum;
 
+#ifdef GODOT_FFT_STAMPS
+__device__ unsigned long long g_stamps[2][4096][16];
+#define STAMP(K, W, I) do { if ((W) < 4096 && threadIdx.x == 0) g_stamps[K][W][I] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(K, W, I) do { } while (0)
+#endif
+
 namespace {
 
-#ifndef ROWS_PREFETCH
-#define ROWS_PREFETCH 1
-#endif
-#ifndef ROWS_PREFETCH_F2
-#define ROWS_PREFETCH_F2 1
-#endif
 constexpr int R1 = 1024;        // points of a column transform after the pruned first stage
 constexpr int ROWS = 16 * R1;   // R
 constexpr int HALF = ROWS / 2;  // rows 0 .. HALF are stored
@@ -216,11 +218,13 @@ struct GatherArgs {
     GatherSeries s[5];
 };
 
-constexpr int GC = 64, GR = 64;   // columns and rows of a workgroup's patch
+constexpr int GC = 32, GR = 128;   // columns and rows of a workgroup's patch
 
+// XB[b][r_hi][i / 2][t][i % 2] for row r = R1 r_hi + TA i + t: the two samples a lane of pass A
+// takes for i and i + 1 are one 16-byte load.  A patch is the rows of two values of i.
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
 {
-    __shared__ double patch[GR][GC + 4];
+    __shared__ double patch[GR][GC + 2];
     const int w = blockIdx.x;
     int si = 0;
 #pragma unroll
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
     const int b0 = (wl % ncb) * GC, r0 = (wl / ncb) * GR;
     const int tid = threadIdx.x;
     {
-        const int col = tid & 63;
-        for (int r = tid >> 6; r < GR; r += 4) {
+        const int col = tid & 31;
+        for (int r = tid >> 5; r < GR; r += 8) {
             const int64_t n = (int64_t)S.B * (r0 + r) + b0 + col;
             double x = 0.0;
             if (n < S.n_in) {
@@ -244,9 +248,11 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
         }
     }
     __syncthreads();
-    const int r = tid & 63;
+    // rows r0 .. r0 + 127 = (i, i + 1) x 64 lanes: element 2 t + (i & 1) of the pair's 128 doubles
+    const int e = tid & 127;
+    const int r = (e & 1) * 64 + (e >> 1);
 #pragma unroll 4
-    for (int col = tid >> 6; col < GC; col += 4) S.XB[(int64_t)(b0 + col) * S.rr + r0 + r] = patch[r][col];
+    for (int col = tid >> 7; col < GC; col += 2) S.XB[(int64_t)(b0 + col) * S.rr + r0 + e] = patch[r][col];
 }
 
 // ---- pass A --------------------------------------------------------------------------------
@@ -265,18 +271,20 @@ struct ColumnArgs {
     int nwg;           // workgroups with work (the grid is rounded up to a multiple of 8)
 };
 
-constexpr int NC = 4;                          // columns per workgroup
+constexpr int NC = 8;                          // columns per workgroup: 128-byte pieces of a row
 constexpr int TA = R1 / 16;                    // threads per column: one wavefront
 static_assert(TA == 64, "columns_kernel gives every column to one wavefront");
 constexpr int COL_REGION = 16 * Team<TA>::RS;  // doubles per wavefront: an exchange of real or imaginary parts,
                                                // or half of the column's results (512 complex numbers)
-constexpr int COL_STAGE = R1 / 2 + 4;          // complex numbers per column while a half is written out:
+constexpr int COL_STAGE = R1 / 2 + 2;          // complex numbers per column while a half is written out:
                                                // the columns of one row on different banks
 static_assert(2 * COL_STAGE <= COL_REGION, "half of a column's results fit its wavefront's region");
 
-__global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
+constexpr int NCL = 1;                         // classes per workgroup
+
+__global__ __launch_bounds__(NCL *NC *TA, 2) void columns_kernel(ColumnArgs a)
 {
-    __shared__ double lds[NC * COL_REGION];
+    __shared__ double lds_all[NCL * NC * COL_REGION];
     // workgroups are dealt to the eight XCDs in turn: give each XCD a contiguous range
     const int per = gridDim.x >> 3;
     const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -287,19 +295,21 @@ __global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
         if (i < a.nseries && w >= a.s[i - 1].wg_end) si = i;
     const ColumnSeries &S = a.s[si];
     const int wl = w - (si ? a.s[si - 1].wg_end : 0);
-    // two adjacent tiles class by class: their 64-byte pieces of a row are written together,
-    // and the block of samples is read nine times while the XCD's L2 still holds it
-    const int c = (wl % 18) >> 1;         // class: rows m = c and 16 - c (mod 16)
+    // Two adjacent tiles follow each other class by class: their pieces of a row are written
+    // together, and the samples are read again while the XCD's L2 still holds them.
+    const int sub = 0, tid = threadIdx.x;
+    const int c = (wl % 18) >> 1;                     // class: rows m = c and 16 - c (mod 16)
     const int tile = (wl / 18) * 2 + (wl & 1);
     const int b0 = tile * NC;
-    const int tid = threadIdx.x;
+    double *lds = lds_all + sub * (NC * COL_REGION);
     const int jj = tid / TA, t = tid % TA;   // a wavefront per column: no workgroup barrier inside the transform
+    STAMP(0, w, 0);
     const int B = S.B;
     cplx v[16];
     {
         // E_c[r_lo], r_lo = t + TA i
         const int nhi = S.nhi;
-        const double *xb = S.XB + (int64_t)(b0 + jj) * nhi * R1 + t;
+        const double *xb = S.XB + (int64_t)(b0 + jj) * nhi * R1 + 2 * t;
         double xt = -(double)((t * c) & (ROWS - 1)) / (double)ROWS;
         xt -= rint(xt);
         cplx tw = expi_cycles(xt);                                   // W_R^(t c)
@@ -312,20 +322,27 @@ __global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
             const cplx wr = w16_any(rh * c);     // W_16^(r_hi c)
             double x[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = xb[TA * i + R1 * rh];
+            for (int i = 0; i < 16; i += 2) {
+                const double2 xx = *(const double2 *)(xb + TA * i + R1 * rh);   // samples i and i + 1
+                x[i] = xx.x;
+                x[i + 1] = xx.y;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 v[i].x = fma(x[i], wr.x, v[i].x);
                 v[i].y = fma(x[i], wr.y, v[i].y);
             }
         }
+        STAMP(0, w, 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             v[i] = cmul(v[i], tw);
             tw = cmul(tw, step);
         }
     }
+    STAMP(0, w, 2);
     wave_fft1024(v, lds + jj * COL_REGION, t);
+    STAMP(0, w, 3);
     // v[4 h + q] = C[mu], mu = u1 + 16 (g + 4 h) + 256 q.  The halves mu < R1/2 (q < 2) and
     // mu >= R1/2 go through LDS one after the other: every wavefront lays its half down in
     // natural order, then adjacent lanes write the NC adjacent columns of a row.
@@ -340,11 +357,13 @@ __global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
     xs -= rint(xs);
     const cplx step = expi_cycles(xs);
     __syncthreads();   // the staged columns lie across the wavefronts' exchange regions: all transforms are done
+    STAMP(0, w, 4);
 #pragma unroll
     for (int h = 0; h < 4; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) stage[jj * COL_STAGE + u1 + 16 * (g + 4 * h) + 256 * q] = v[h * 4 + q];
     __syncthreads();
+    STAMP(0, w, 5);
     {
         // mu = s + TA h < R1/2: row c + 16 mu
         double x0 = -(double)((b * (c + 16 * s)) & (L - 1)) * invL;
@@ -359,12 +378,16 @@ __global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
         }
     }
     __syncthreads();
+    STAMP(0, w, 6);
+    // the upper half: classes 0 and 8 are their own partners and have nothing to write from it
+    // but row R/2 (class 0), yet they go through the barrier with the others
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int q = 2; q < 4; ++q) stage[jj * COL_STAGE + u1 + 16 * (g + 4 * h) + 256 * (q - 2)] = v[h * 4 + q];
+    __syncthreads();
+    STAMP(0, w, 7);
     if (c != 0 && c != 8) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int q = 2; q < 4; ++q) stage[jj * COL_STAGE + u1 + 16 * (g + 4 * h) + 256 * (q - 2)] = v[h * 4 + q];
-        __syncthreads();
         // mu = R1/2 + s + TA h: conj -> row (16 - c) + 16 (R1 - 1 - mu); rows step down
         const int row8 = (16 - c) + 16 * (R1 / 2 - 1 - s);
         double x0 = -(double)((b * row8) & (L - 1)) * invL;
@@ -377,15 +400,14 @@ __global__ __launch_bounds__(NC *TA, 4) void columns_kernel(ColumnArgs a)
             V[(int64_t)(row8 - 16 * TA * h) * B + b] = cmul(cplx{z.x, -z.y}, wv);
             wv = cmul(wv, back);
         }
-    } else if (c == 0) {
-        // row R/2 = 16 * (R1/2): C[R1/2] is with lane u1 = 0, g = 0 as v[0 * 4 + 2]
-        if (t == 0) {
-            const int64_t bc = b0 + jj;
-            double xh = -(double)((bc * HALF) & (L - 1)) * invL;
-            xh -= rint(xh);
-            V[(int64_t)HALF * B + bc] = cmul(v[2], expi_cycles(xh));
-        }
+    } else if (c == 0 && s == 0) {
+        // row R/2 = 16 * (R1/2): C[R1/2] is the first of the staged upper half
+        const cplx z = stage[jw * COL_STAGE];
+        double xh = -(double)((b * HALF) & (L - 1)) * invL;
+        xh -= rint(xh);
+        V[(int64_t)HALF * B + b] = cmul(z, expi_cycles(xh));
     }
+    STAMP(0, w, 8);
 }
 
 // ---- zero-frequency values of the second-moment series ----------------------------------
@@ -480,52 +502,29 @@ __global__ __launch_bounds__(512) void rows_kernel(RowArgs a)
         }
     };
 
-#if ROWS_PREFETCH == 0
-    row_load<T2>(v, a.V2[0], (uint32_t)ser2 * a.stride2 + (uint32_t)((m0 + rho2) * B2 + t2), valid2);
-    team_fft16<T2>(v, lds + vr * REG2, t2);
-    real_parts(lds + rho * REG2, g3);
-    real_parts(lds + (NR + rho) * REG2, g4);
-    __syncthreads();
-    row_load<T2>(v, a.V2[2], (uint32_t)((m0 + rho2) * B2 + t2), valid2 && ser2 == 0);
-    team_fft16<T2>(v, lds + vr * REG2, t2);
-    real_parts(lds + rho * REG2, g5);
-    __syncthreads();
-    row_load<T>(v, a.V1[0], (uint32_t)((m0 + rho1) * B + t1), valid1);
-    team_fft16<T>(v, lds + rho1 * REG1, t1);
-    {
-        const cplx *reg = lds + rho * REG1;
-        int sl = s;
-        asm volatile("" : "+v"(sl));
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int p = sl + T * h;
-            f1[h] = reg[p];
-            const cplx z = reg[B - 1 - p];
-            f1[4 + h] = cplx{z.x, -z.y};
-        }
-    }
-    __syncthreads();
-    row_load<T>(v, a.V1[1], (uint32_t)((m0 + rho1) * B + t1), valid1);
-    team_fft16<T>(v, lds + rho1 * REG1, t1);
-#else
+    STAMP(1, g, 0);
     row_load<T2>(v, a.V2[0], (uint32_t)ser2 * a.stride2 + (uint32_t)((m0 + rho2) * B2 + t2), valid2);
     row_load<T2>(nx, a.V2[2], (uint32_t)((m0 + rho2) * B2 + t2), valid2 && ser2 == 0);
+    STAMP(1, g, 1);
     team_fft16<T2>(v, lds + vr * REG2, t2);
+    STAMP(1, g, 2);
     real_parts(lds + rho * REG2, g3);
     real_parts(lds + (NR + rho) * REG2, g4);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
     row_load<T>(nx, a.V1[0], (uint32_t)((m0 + rho1) * B + t1), valid1);
+    STAMP(1, g, 3);
     team_fft16<T2>(v, lds + vr * REG2, t2);
+    STAMP(1, g, 4);
     real_parts(lds + rho * REG2, g5);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
-#if ROWS_PREFETCH_F2
     row_load<T>(nx, a.V1[1], (uint32_t)((m0 + rho1) * B + t1), valid1);
-#endif
+    STAMP(1, g, 5);
     team_fft16<T>(v, lds + rho1 * REG1, t1);
+    STAMP(1, g, 6);
     {
         const cplx *reg = lds + rho * REG1;
         int sl = s;
@@ -539,11 +538,9 @@ __global__ __launch_bounds__(512) void rows_kernel(RowArgs a)
         }
     }
     __syncthreads();
-#if !ROWS_PREFETCH_F2
-    row_load<T>(nx, a.V1[1], (uint32_t)((m0 + rho1) * B + t1), valid1);
-#endif
+    STAMP(1, g, 7);
     team_fft16<T>(nx, lds + rho1 * REG1, t1);
-#endif
+    STAMP(1, g, 8);
     if (m > HALF) return;
     const double S2 = a.dc[0], B2v = a.dc[1], SB = a.dc[2];
     const cplx *reg = lds + rho * REG1;
@@ -569,6 +566,132 @@ __global__ __launch_bounds__(512) void rows_kernel(RowArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);   // one pair of bins at a time: interleaving them costs registers
     }
+    STAMP(1, g, 9);
+}
+
+// Rows of 2 048 points (l = 2^25) with every transform done by ONE wavefront, so that no
+// barrier of the workgroup stands inside a transform and the eight wavefronts drift apart:
+// a row of a second-moment series (1 024 points) is one transform; a row of a first-moment
+// series is split into its even and its odd samples, E and O, transformed by two wavefronts,
+// and X[p] = E[p] + W_2048^p O[p], X[p + 1024] = E[p] - W_2048^p O[p] is formed where the
+// estimators pick their bins up.  Barriers remain only between a transform and the reading
+// of its results by the threads of the estimators (adjacent lanes = adjacent rows).
+__global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
+{
+    constexpr int NR = 4, T = 128, B = 2048, B2 = 1024;
+    constexpr int REG = Team<64>::REGION + 4;   // rows of one bin on different banks when the estimators read
+    __shared__ cplx lds[8 * REG];
+    const int tid = threadIdx.x;
+    // The last group holds row R/2 alone and runs through its phases faster than the others (one
+    // wavefront of four has a row): it is the first workgroup, so that it is not the one the
+    // launch ends on.  The others: adjacent groups, which write adjacent bins, on one XCD.
+    const int per = (gridDim.x - 8) >> 3;
+    int g;
+    if (blockIdx.x < 8) {
+        if (blockIdx.x) return;
+        g = a.ngroup - 1;
+    } else {
+        const int w = blockIdx.x - 8;
+        g = (w & 7) * per + (w >> 3);
+        if (g >= a.ngroup - 1) return;   // uniform
+    }
+    const int m0 = g * NR;
+    // a wavefront: row m0 + wr of series (or parity) wh; a thread of the estimators: row
+    // rho = tid % 4 with slot s = tid / 4
+    const int wave = tid >> 6, lane = tid & 63, wr = wave & 3, wh = wave >> 2;
+    const int rho = tid % NR, s = tid / NR;
+    const bool valid = m0 + wr <= HALF;
+    const int m = m0 + rho;
+    cplx *mine = lds + wave * REG;
+    double g3[8], g4[8], g5[8];
+    cplx f1[8];
+    cplx v[16], nx[16];
+
+    auto real_parts = [&](const cplx *reg, double (&gg)[8]) {
+        int sl = s;
+        asm volatile("" : "+v"(sl));
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = sl + T * h;
+            gg[h] = reg[p].x;
+            gg[4 + h] = reg[B2 - 1 - p].x;
+        }
+    };
+    // X[p] and conj X[B - 1 - p], p = s + T h, of a first-moment row from its halves
+    auto combine = [&](cplx (&f)[8]) {
+        int sl = s;
+        asm volatile("" : "+v"(sl));
+        const cplx *E = lds + rho * REG, *O = lds + (NR + rho) * REG;
+        const cplx wd = expi_cycles(-(double)sl / 2048.0);            // W_2048^s
+        const cplx wm = expi_cycles(-(double)(1023 - sl) / 2048.0);   // W_2048^(1023 - s)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = sl + T * h, q = 1023 - p;
+            const cplx r = w16(h);                                   // W_2048^(128 h)
+            const cplx od = cmul(O[p], h ? cmul(wd, r) : wd);
+            f[h] = E[p] + od;
+            const cplx om = cmul(O[q], h ? cmul(wm, cplx{r.x, -r.y}) : wm);
+            const cplx xm = E[q] - om;
+            f[4 + h] = cplx{xm.x, -xm.y};
+        }
+    };
+
+    STAMP(1, g, 0);
+    row_load<64>(v, a.V2[0], (uint32_t)wh * a.stride2 + (uint32_t)((m0 + wr) * B2 + lane), valid);
+    row_load<64>(nx, a.V2[2], (uint32_t)((m0 + wr) * B2 + lane), valid && wh == 0);
+    STAMP(1, g, 1);
+    if (valid) team_fft16<64, true>(v, mine, lane);
+    __syncthreads();
+    STAMP(1, g, 2);
+    real_parts(lds + rho * REG, g3);
+    real_parts(lds + (NR + rho) * REG, g4);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = nx[i];
+    // even (wh = 0) or odd (wh = 1) samples of the row
+    row_load<128>(nx, a.V1[0], (uint32_t)((m0 + wr) * B + 2 * lane + wh), valid);
+    STAMP(1, g, 3);
+    if (wh == 0 && valid) team_fft16<64, true>(v, mine, lane);
+    __syncthreads();
+    STAMP(1, g, 4);
+    real_parts(lds + rho * REG, g5);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = nx[i];
+    row_load<128>(nx, a.V1[1], (uint32_t)((m0 + wr) * B + 2 * lane + wh), valid);
+    STAMP(1, g, 5);
+    if (valid) team_fft16<64, true>(v, mine, lane);
+    __syncthreads();
+    STAMP(1, g, 6);
+    combine(f1);
+    __syncthreads();
+    STAMP(1, g, 7);
+    if (valid) team_fft16<64, true>(nx, mine, lane);
+    __syncthreads();
+    STAMP(1, g, 8);
+    if (m > HALF) return;
+    cplx f2[8];
+    combine(f2);
+    const double S2 = a.dc[0], B2v = a.dc[1], SB = a.dc[2];
+    int sl = s;
+    asm volatile("" : "+v"(sl));
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int p = sl + T * h;
+        const int64_t k = m + (int64_t)ROWS * p;
+        ps_estimators(k, a.nk, f1[h].x, -f1[h].y, f2[h].x, -f2[h].y, S2, B2v, SB, g3[h], g4[h], g5[h], a.p0, a.p1,
+                      a.pb, a.amps);
+        // X[(R - m) + R p] = conj of output B - 1 - p; row 0 reaches only the bin l/4 this way,
+        // row R/2 is its own mirror
+        const bool mir = (m > 0 && m < HALF) || (m == 0 && p == B / 4 - 1);
+        if (mir) {
+            const int64_t km = (ROWS - m) + (int64_t)ROWS * p;
+            ps_estimators(km, a.nk, f1[4 + h].x, -f1[4 + h].y, f2[4 + h].x, -f2[4 + h].y, S2, B2v, SB, g3[4 + h],
+                          g4[4 + h], g5[4 + h], a.p0, a.p1, a.pb, a.amps);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one pair of bins at a time: interleaving them costs registers
+    }
+    STAMP(1, g, 9);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -617,7 +740,7 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
         const int Bs = i < 3 ? B / 2 : B;
         int nhi = (int)ceil_div(n, L / 16);
         if (nhi > 16) nhi = 16;
-        end += (Bs / NC) * 9;
+        end += (Bs / NC) * (9 / NCL);
         gend += (Bs / GC) * (nhi * R1 / GR);
         ga.s[i] = GatherSeries{sa[i], sb[i], n, xb, Bs, nhi * R1, gend};
         ca.s[i] = ColumnSeries{xb, L, sv[i], Bs, nhi, end};
@@ -627,13 +750,13 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
     ca.nseries = 5;
     ca.nwg = end;
     const unsigned gridA = (unsigned)(ceil_div(end, 8) * 8);
-    hipLaunchKernelGGL(columns_kernel, dim3(gridA), dim3(NC * TA), 0, st, ca);
+    hipLaunchKernelGGL(columns_kernel, dim3(gridA), dim3(NCL * NC * TA), 0, st, ca);
     hipLaunchKernelGGL(rows_dc_kernel, dim3(1), dim3(256), 0, st, (const cplx *)V3, (const cplx *)V4,
                        (const cplx *)V5, B / 2, dc);
     RowArgs ra{{V1a, V1b}, {V3, V4, V5}, dc, p0, p1, pb, amps, l / 4 + 1, 0, (uint32_t)(sz2 / sizeof(cplx))};
     if (B == 2048) {
         ra.ngroup = HALF / 4 + 1;
-        hipLaunchKernelGGL(rows_kernel<128>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
+        hipLaunchKernelGGL(rows2048_kernel, dim3((unsigned)(8 + ceil_div(ra.ngroup - 1, 8) * 8)), dim3(512), 0, st, ra);
     } else {
         ra.ngroup = HALF / 8 + 1;
         hipLaunchKernelGGL(rows_kernel<64>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
@@ -641,3 +764,10 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
 }
 
 }   // namespace godot_spectrum
+
+#ifdef GODOT_FFT_STAMPS
+extern "C" int godot_debug_fft_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif

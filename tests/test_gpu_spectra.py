@@ -297,3 +297,51 @@ def test_spectrum_whose_last_pass_forms_the_estimators(lg, frac):
     ramps = np.asarray(ramps)
     sc = np.abs(ramps[:, 1:]).max(axis=1, keepdims=True)
     assert (np.abs(got[:, 1:] - ramps[:, 1:]) <= 1e-8 * sc).all()
+
+
+@pytest.mark.parametrize('lg,nbin', [(24, 1_893_456), (24, 700), (24, 1 << 23), (24, 1_048_577),
+                                     (25, 3_786_912), (25, 1 << 24), (25, 5000)])
+def test_long_series_transformed_by_columns_and_rows(lg, nbin):
+    """Padded lengths 2^24 and 2^25 take the path of two trips through memory (columns of the
+    padded series, then rows with the estimators): every bin and the amplitudes against numpy's
+    transforms, and against the three-trip path of the same library, for series that fill a
+    tenth of the padded length (the default padding), half of it (the most the path takes: every
+    sixteenth of a column holds samples), a short series (not a shorter one: the lowest bins of
+    a few samples in 2^24 are a quotient of two rounding errors in numpy as well), and one
+    sample past a sixteenth."""
+    import os
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(500 + lg + nbin % 97)
+    l = 1 << lg
+    cnt = rng.poisson(3.0, nbin).astype(float)
+    W = cnt * rng.uniform(0.1, 0.3, nbin)
+    WW = W * rng.uniform(0.2, 0.6, nbin)
+    S = rng.uniform(0.5, 1.5, nbin) * max(W.mean(), 0.1)
+    B = rng.uniform(0.5, 1.5, nbin) * max((cnt - W).mean(), 0.1)
+    Wb, WbWb = cnt - W, cnt - 2 * W + WW
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = (d(W), d(WW), d(S), d(Wb), d(WbWb), d(B), l)
+    q0, q1, qb, qamps = ops.power_spectrum_fft(*args, want_amps=True)
+    os.environ['GODOT_FFT_THREE_TRIPS'] = '1'
+    try:
+        o0, o1, ob, oamps = ops.power_spectrum_fft(*args, want_amps=True)
+    finally:
+        del os.environ['GODOT_FFT_THREE_TRIPS']
+    nk = l // 4 + 1
+    f = [np.fft.rfft(x, n=l) for x in (W - S, Wb - B, WW, WbWb, W - WW)]
+    parts = (f[0][:nk], f[1][:nk], f[2][::2], f[3][::2], f[4][::2])
+    del f
+    with np.errstate(all='ignore'):
+        r0, r1, rb = orc.power_spectrum_from_parts(*parts)
+        ramps = np.asarray(orc.power_spectrum_from_parts(*parts, get_amps=True))
+    assert q0.numel() == nk
+    for got, old, ref in ((q0, o0, r0), (q1, o1, r1), (qb, ob, rb)):
+        got, old = got.cpu().numpy(), old.cpu().numpy()
+        sc = np.abs(ref[1:]).max()
+        assert np.abs(got[1:] - ref[1:]).max() <= 1e-9 * sc
+        assert np.abs(got[1:] - old[1:]).max() <= 1e-9 * sc
+        assert np.isnan(got[0]) == np.isnan(ref[0]) and (np.isnan(ref[0]) or abs(got[0] - ref[0]) <= 1e-9 * sc)
+    got = qamps.cpu().numpy()
+    sc = np.abs(ramps[:, 1:]).max(axis=1, keepdims=True)
+    assert (np.abs(got[:, 1:] - ramps[:, 1:]) <= 1e-8 * sc).all()
