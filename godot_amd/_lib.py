@@ -48,6 +48,10 @@ SIGNATURES = {
     'godot_version': (c_int, []),
     'godot_cell_fit': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,
                                         c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_cell_fit_shaped': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_i64, c_f64p, c_f64, c_f64p, c_f64,
+                                               c_int, c_f64p, c_f64p, c_i32p, c_stream]),
+    'godot_cell_logpdf_shaped': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_i64, c_f64p, c_f64, c_int, c_int,
+                                                  c_int, c_f64p, c_f64p, c_i32p, c_stream]),
     'godot_cell_loglike': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_int, c_f64p, c_stream]),
     'godot_cell_logpdf': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_int, c_int,
                                            c_int, c_f64p, c_f64p, c_i32p, c_stream]),

@@ -125,12 +125,15 @@ class CellBatch(object):
     """Device-resident list of cells; behaves like the list of Cell objects
     the reference's Data.get_cells returns (len, indexing, iteration)."""
 
-    def __init__(self, we, ti, lo, hi, starts, stops, sexp, bexp, phase=False):
+    def __init__(self, we, ti, lo, hi, starts, stops, sexp, bexp, phase=False, photons=None):
         self.we, self.ti, self.lo, self.hi = we, ti, lo, hi
         self.starts, self.stops, self.sexp, self.bexp = starts, stops, sexp, bexp
         self.device = we.device
         self.phase = bool(phase)      # cells of a folded light curve: indexing yields PhaseCell
         self._host = None
+        # photons inside the cells (sum of hi - lo): what the kernels size their shape for; None
+        # until someone knows it (ops.CellRanges counts it at the first fit and tells us)
+        self._photons = None if photons is None else int(photons)
 
     @classmethod
     def from_cells(cls, cells, device=None):
@@ -150,11 +153,13 @@ class CellBatch(object):
         offd = _to_dev(off, dev, I64)
         return cls(_to_dev(we, dev), _to_dev(ti, dev), offd[:-1], offd[1:],
                    _to_dev([c.tstart for c in cells], dev), _to_dev([c.tstop for c in cells], dev),
-                   _to_dev(sexp, dev), _to_dev(bexp, dev))
+                   _to_dev(sexp, dev), _to_dev(bexp, dev), photons=int(off[-1]))
 
     def ranges(self):
-        return ops.CellRanges(self.we, self.lo.contiguous(), self.hi.contiguous(), self.sexp,
-                              self.bexp)
+        cr = ops.CellRanges(self.we, self.lo.contiguous(), self.hi.contiguous(), self.sexp,
+                            self.bexp, photons=self._photons)
+        cr._owner = self              # a count made later is kept here too
+        return cr
 
     def __len__(self):
         return self.lo.numel()
@@ -167,9 +172,15 @@ class CellBatch(object):
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return CellBatch(self.we, self.ti, self.lo[i].contiguous(), self.hi[i].contiguous(),
+            lo = self.lo[i].contiguous()
+            # a slice is taken to be as densely filled as the whole, if that is known
+            photons = None
+            if self._photons is not None and len(self):
+                photons = int(round(self._photons * (lo.numel() / len(self))))
+            return CellBatch(self.we, self.ti, lo, self.hi[i].contiguous(),
                              self.starts[i].contiguous(), self.stops[i].contiguous(),
-                             self.sexp[i].contiguous(), self.bexp[i].contiguous(), phase=self.phase)
+                             self.sexp[i].contiguous(), self.bexp[i].contiguous(), phase=self.phase,
+                             photons=photons)
         h = self._hostcopy()
         n = len(h['lo'])
         if i < 0:
@@ -1522,7 +1533,8 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         if any(not tc > 0 or nc < 1 for _, _, tc, nc in spans):
             spans = None         # a span that ends before it begins: whatever get_cells makes of it
     if spans is None:
-        per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=False,
+        # one source after another, each trimmed by its own call (on its exposure, as below)
+        per = [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
                            use_barycenter=False, quiet=quiet) for d in sources]
         nph = np.array([b.we.numel() for b in per], dtype=np.int64)
         ncl = np.array([len(b) for b in per], dtype=np.int64)
@@ -1532,6 +1544,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         lo, hi = cat('lo') + shift, cat('hi') + shift
         starts, stops, sexp, bexp = cat('starts'), cat('stops'), cat('sexp'), cat('bexp')
         source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
+        we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
     else:
         build_exposure_tables(sources)              # those still to build: over several streams
         desc = []
@@ -1539,15 +1552,17 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
             desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
                              table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
                              t0=t0, tcell=tc, ncell=nc))
-        starts, stops, _, sexp, bexp, _, lo, hi, source = ops.bin_sources(desc)
+        starts, stops, exp, sexp, bexp, _, lo, hi, source = ops.bin_sources(desc)
         ncl = np.array([s['ncell'] for s in desc], dtype=np.int64)
-    we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
-    if trim_zero_exposure:
-        # a cell has exposure exactly when it has source exposure (sexp = S / E * exp, S > 0)
-        keep = ops.select_cells(sexp, 0.0)                     # the one wait of the batch
-        lo, hi, starts, stops, sexp, bexp, source = ops.gather_columns(
-            [c.contiguous() for c in (lo, hi, starts, stops, sexp, bexp, source)], keep)
-        ncl = _kept_per_source(keep, ncl)
+        we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
+        if trim_zero_exposure:
+            # on the exposure itself, as the reference does (core.py:2110-2122): exposure and source
+            # exposure are differences of two separately rounded running sums, so that beside a gap
+            # one of them can be zero and the other an ulp (and with S = 0 every sexp is zero)
+            keep = ops.select_cells(exp, 0.0)                      # the one wait of the batch
+            lo, hi, starts, stops, sexp, bexp, source = ops.gather_columns(
+                [c.contiguous() for c in (lo, hi, starts, stops, sexp, bexp, source)], keep)
+            ncl = _kept_per_source(keep, ncl)
     cells = CellBatch(we, ti, lo.contiguous(), hi.contiguous(), starts, stops, sexp, bexp)
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
 

@@ -800,6 +800,16 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
     return GODOT_OK;
 }
 
+extern "C" int godot_cell_fit_shaped(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                     const double *S, const double *B, int64_t ncell, int64_t photons_in_cells,
+                                     const double *guess, double guess0, const double *beta, double beta0,
+                                     int swap, double *alpha, double *ts, int32_t *flags, godot_stream_t stream)
+{
+    GODOT_REQUIRE(photons_in_cells >= 0, GODOT_E_INVALID, "godot_cell_fit_shaped: negative photon count");
+    GodotShapeHint hint(photons_in_cells);
+    return godot_cell_fit(we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap, alpha, ts, flags, stream);
+}
+
 extern "C" int godot_cell_loglike(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                                   const double *S, const double *B, int64_t ncell,
                                   const double *alpha, int swap, double *logl, godot_stream_t stream)
@@ -904,6 +914,17 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     }
     GODOT_LAUNCH_CHECK("godot_cell_logpdf");
     return GODOT_OK;
+}
+
+extern "C" int godot_cell_logpdf_shaped(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                        const double *S, const double *B, int64_t ncell, int64_t photons_in_cells,
+                                        const double *aopt, double dlogl, int npt, int include_zero, int swap,
+                                        double *dom, double *cod, int32_t *flags, godot_stream_t stream)
+{
+    GODOT_REQUIRE(photons_in_cells >= 0, GODOT_E_INVALID, "godot_cell_logpdf_shaped: negative photon count");
+    GodotShapeHint hint(photons_in_cells);
+    return godot_cell_logpdf(we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero, swap, dom, cod, flags,
+                             stream);
 }
 
 extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int64_t ncell, int npt,

@@ -852,7 +852,7 @@ int spread_width(int dev, int64_t nph, int64_t ncell)
     }
     if (g_order.cus[dev] <= 0) return 0;
     int64_t width = g_order.cus[dev] / ncell;     // one workgroup per compute unit at most
-    const int64_t by_size = nph / ncell / SP_MIN_SHARE;
+    const int64_t by_size = godot_shape_photons(nph) / ncell / SP_MIN_SHARE;
     if (width > by_size) width = by_size;
     if (width > SP_MAX_G) width = SP_MAX_G;
     if (width * ncell > SP_MAX_WG) width = SP_MAX_WG / ncell;
@@ -922,7 +922,7 @@ namespace godot_detail {
 // cells of this mean size and above get a workgroup each
 bool block_cells(int64_t nph, int64_t ncell)
 {
-    return ncell > 0 && (double)nph >= 16384.0 * (double)ncell;
+    return ncell > 0 && (double)godot_shape_photons(nph) >= 16384.0 * (double)ncell;
 }
 
 // Fits take a workgroup per cell also where the cells are well beyond the registers of a
@@ -933,7 +933,7 @@ bool block_cells(int64_t nph, int64_t ncell)
 // 9 588: 0.102 by workgroups (dense about 0.17); 13 699: 0.076 (dense about 0.24).
 bool fit_block_cells(int64_t nph, int64_t ncell)
 {
-    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)nph >= 6500.0 * (double)ncell);
+    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)godot_shape_photons(nph) >= 6500.0 * (double)ncell);
 }
 
 // Profile grids take a workgroup per cell also where the cells are only moderately large but
@@ -941,7 +941,7 @@ bool fit_block_cells(int64_t nph, int64_t ncell)
 // such workgroups most SIMDs hold a single wavefront and nothing hides its latencies.
 bool logpdf_block_cells(int64_t nph, int64_t ncell)
 {
-    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)nph >= 1024.0 * (double)ncell);
+    return block_cells(nph, ncell) || (ncell > 0 && ncell <= 4096 && (double)godot_shape_photons(nph) >= 1024.0 * (double)ncell);
 }
 
 void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,

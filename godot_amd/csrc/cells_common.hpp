@@ -876,7 +876,7 @@ __device__ double fit_beta(const CD &cd, double B, double alpha, double guess, i
 // possible (fewer reduction steps, more cells per wavefront).
 inline int pick_team(int64_t nph, int64_t ncell)
 {
-    double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
+    double mean = ncell > 0 ? (double)godot_shape_photons(nph) / (double)ncell : 0.0;
     double need = mean + 4.0 * sqrt(mean) + 8.0;
     // T x R register slots, in steps of a quarter to a half: a shape twice too large
     // spends half of every pass on padding

@@ -930,7 +930,7 @@ namespace godot_detail {
 // Returns false when no shape holds the cells.
 bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid)
 {
-    const double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
+    const double mean = ncell > 0 ? (double)godot_shape_photons(nph) / (double)ncell : 0.0;
     const double need = mean + 2.0 * sqrt(mean), wide = mean + 3.0 * sqrt(mean);
     if (need <= 9.0) { L = 1; R = 8; }
     else if (need <= 17.0) { L = 1; R = 16; }
@@ -969,7 +969,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     // Sparse cells restart often (1 in 10 at four photons per cell, 1 in 40 at
     // twelve): their restarts go to the second kernel.  From about sixteen photons
     // per cell on about 1 in 100 restarts and repeating in place is cheaper.
-    const bool inplace = (double)nph >= 16.0 * (double)ncell;
+    const bool inplace = (double)godot_shape_photons(nph) >= 16.0 * (double)ncell;
     dim3 grid((unsigned)ceil_div(ncell, (int64_t)(64 / L))), block(64);
     dim3 grid2((unsigned)ceil_div(ncell, (int64_t)GK_SCAN));
 #define GK_LAUNCH_INPLACE(L_, R_)                                                                   \

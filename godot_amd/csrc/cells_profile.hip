@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void cell_logpdf_profile_kernel(CellArgs p, co
 
 inline int pick_stream_team(int64_t nph, int64_t ncell)
 {
-    double mean = ncell > 0 ? (double)nph / (double)ncell : 0.0;
+    double mean = ncell > 0 ? (double)godot_shape_photons(nph) / (double)ncell : 0.0;
     if (mean <= 40) return 4;
     if (mean <= 400) return 16;
     return 64;

@@ -35,6 +35,16 @@ void godot_set_error(const char *fmt, ...);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// The number of photons the cell kernels size their shape for (lanes and register slots per
+// cell): the length of the weight array, unless the entry point was told how many photons lie
+// inside the cells (the godot_*_shaped entry points; a subset of cells handed over with the
+// whole weight array would otherwise get a shape for cells many times their size).
+int64_t godot_shape_photons(int64_t nph);
+struct GodotShapeHint {
+    explicit GodotShapeHint(int64_t photons_in_cells);
+    ~GodotShapeHint();
+};
+
 // ---- device side -----------------------------------------------------------
 constexpr int WAVE = 64;
 

@@ -103,9 +103,9 @@ def fit_cells_sharded(counts, fit_fn, group=None):
     counts : host array of photons per cell (same on every rank)
     fit_fn : callable(first_cell, last_cell) -> (n_local, k) tensor of per-cell
              records (e.g. alpha, TS, flags) computed on this rank's device; it
-             should fit ops.CellRanges.shard(first_cell, last_cell), i.e. hand the
-             kernels the rank's slice of the photons, not the whole list (they
-             take photons per cell from the length of the weight array)
+             should fit ops.CellRanges.shard(first_cell, last_cell, photons=counts[first_cell:
+             last_cell].sum()): the shard keeps the whole weight array and tells the kernels
+             how many photons its own cells hold (they size their shape for that)
     """
     c0, c1 = cell_shard(counts, group=group)
     rec = fit_fn(c0, c1)

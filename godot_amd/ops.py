@@ -39,9 +39,15 @@ def _stream(dev):
 
 
 class CellRanges(object):
-    """Device view of many cells: weights + per-cell photon ranges + S, B."""
+    """Device view of many cells: weights + per-cell photon ranges + S, B.
 
-    def __init__(self, we, lo, hi, S, B):
+    photons   how many photons lie inside the cells (sum of hi - lo), which is what the fit and
+              profile kernels size their shape for; None: counted on the device at the first
+              call that needs it (one small read, once per object).  A subset of cells keeps the
+              whole weight array and carries its own count, so it is fitted with the shape of
+              its own cells, not of cells as large as the array is long."""
+
+    def __init__(self, we, lo, hi, S, B, photons=None):
         _dev_check(we, F64, 'we')
         _dev_check(lo, I64, 'lo')
         _dev_check(hi, I64, 'hi')
@@ -54,6 +60,16 @@ class CellRanges(object):
         self.ncell = n
         self.nph = we.numel()
         self.device = we.device
+        self._photons = None if photons is None else int(photons)
+
+    @property
+    def photons(self):
+        if self._photons is None:
+            self._photons = int((self.hi - self.lo).sum().item()) if self.ncell else 0
+            owner = getattr(self, '_owner', None)
+            if owner is not None:
+                owner._photons = self._photons
+        return self._photons
 
     @classmethod
     def from_offsets(cls, we, offsets, S, B):
@@ -63,21 +79,17 @@ class CellRanges(object):
     def _head(self):
         return (_p(self.we), self.nph, _p(self.lo), _p(self.hi))
 
-    def shard(self, c0, c1):
-        """Cells [c0, c1) as a view of their own: the weights are narrowed to the
-        photons those cells can reach and the ranges shifted accordingly.  The
-        kernels choose their shape from photons per cell, which they take from
-        the length of the weight array, so a rank should hand over its slice and
-        not the whole list.  One device-to-host read."""
-        lo, hi = self.lo[c0:c1], self.hi[c0:c1]
-        if lo.numel() == 0:
-            return CellRanges(self.we[:0], lo.contiguous(), hi.contiguous(), self.S[c0:c1].contiguous(),
-                              None if self.B is None else self.B[c0:c1].contiguous())
-        a, b = (int(x) for x in torch.stack([lo.min(), hi.max()]).cpu())
-        a = min(max(a, 0), self.nph)
-        b = min(max(b, a), self.nph)
-        return CellRanges(self.we[a:b], (lo - a).contiguous(), (hi - a).contiguous(),
-                          self.S[c0:c1].contiguous(), None if self.B is None else self.B[c0:c1].contiguous())
+    def shard(self, c0, c1, photons=None):
+        """Cells [c0, c1) as a view of their own, over the same weight array.  photons: how
+        many photons the shard's cells hold if the caller knows (a split balanced by photon
+        count does); otherwise the shard is taken to be as densely filled as the whole.
+        Nothing is read back from the device."""
+        n = max(0, min(c1, self.ncell) - max(c0, 0))
+        if photons is None and self._photons is not None and self.ncell:
+            photons = int(round(self._photons * (n / self.ncell)))
+        return CellRanges(self.we, self.lo[c0:c1].contiguous(), self.hi[c0:c1].contiguous(),
+                          self.S[c0:c1].contiguous(), None if self.B is None else self.B[c0:c1].contiguous(),
+                          photons=photons)
 
 
 def _per_cell(x, n, dev, name):
@@ -100,7 +112,7 @@ def cell_fit(cr, guess=1.0, beta=1.0, swap=False, want_ts=True):
     ts = torch.empty(n, dtype=F64, device=dev) if want_ts else None
     flags = torch.empty(n, dtype=I32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call('godot_cell_fit', *cr._head(), _p(cr.S), _p(cr.B), n, _p(gt), g0, _p(bt), b0,
+        _lib.call('godot_cell_fit_shaped', *cr._head(), _p(cr.S), _p(cr.B), n, cr.photons, _p(gt), g0, _p(bt), b0,
                   int(bool(swap)), _p(alpha), _p(ts), _p(flags), _stream(dev))
     return alpha, ts, flags
 
@@ -141,7 +153,7 @@ def cell_logpdf(cr, aopt=None, dlogl=20., npt=100, include_zero=False, swap=Fals
     cod = torch.empty((n, npt), dtype=F64, device=dev)
     flags = torch.empty(n, dtype=I32, device=dev)
     with torch.cuda.device(dev):
-        _lib.call('godot_cell_logpdf', *cr._head(), _p(cr.S), _p(cr.B), n, _p(aopt), float(dlogl),
+        _lib.call('godot_cell_logpdf_shaped', *cr._head(), _p(cr.S), _p(cr.B), n, cr.photons, _p(aopt), float(dlogl),
                   int(npt), int(bool(include_zero)), int(bool(swap)), _p(dom), _p(cod), _p(flags),
                   _stream(dev))
     return dom, cod, flags

@@ -80,6 +80,21 @@ int godot_cell_fit(const double *we, int64_t nph,
                    double *alpha, double *ts, int32_t *flags,
                    godot_stream_t stream);
 
+/* godot_cell_fit told how many photons lie inside the cells (the sum of hi - lo).  The
+ * kernels choose how many lanes and registers a cell gets from the mean number of photons
+ * per cell, which godot_cell_fit takes to be nph / ncell; a subset of the cells handed over
+ * with the whole weight array (a slice of a cell list, one rank's share) would get a shape
+ * for cells many times their size.  Same results: the choice changes speed only.  The
+ * reference fits cell by cell (core.py:1087-1095) and has no counterpart of the choice.   */
+int godot_cell_fit_shaped(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                          const double *S, const double *B, int64_t ncell,
+                          int64_t photons_in_cells,
+                          const double *guess, double guess0,
+                          const double *beta, double beta0, int swap,
+                          double *alpha, double *ts, int32_t *flags,
+                          godot_stream_t stream);
+
 /* logL(alpha_c) of every cell: CellLogLikelihood.log_likelihood
  * (core.py:353-364).  alpha is per cell.                                      */
 int godot_cell_loglike(const double *we, int64_t nph,
@@ -100,6 +115,17 @@ int godot_cell_logpdf(const double *we, int64_t nph,
                       int include_zero, int swap,
                       double *dom, double *cod, int32_t *flags,
                       godot_stream_t stream);
+/* godot_cell_logpdf told how many photons lie inside the cells; see
+ * godot_cell_fit_shaped.                                                        */
+int godot_cell_logpdf_shaped(const double *we, int64_t nph,
+        const int64_t *lo, const int64_t *hi,
+                             const double *S, const double *B, int64_t ncell,
+                             int64_t photons_in_cells,
+                             const double *aopt, double dlogl, int npt,
+                             int include_zero, int swap, double *dom,
+                             double *cod, int32_t *flags,
+                             godot_stream_t stream);
+
 
 /* Post-processing of the cached profiles: CellsLogLikelihood.get_flux
  * (core.py:1229, 1247-1256).  aguess = dom[argmax cod]; xlo/xhi = quantiles

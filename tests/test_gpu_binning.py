@@ -269,6 +269,30 @@ def test_cells_of_many_sources_in_one_call_equal_the_per_source_calls(tcell, spa
         assert_same(_n(one.cells.sexp)[c0:c1], b['sexp'], "b['sexp']")
 
 
+def test_batch_trims_on_exposure_as_the_single_source_call_does():
+    """The cells a batch keeps are those with exposure > 0 (core.py:2110-2122), not those with
+    source exposure > 0: ten-minute cells over orbital gaps, where the two running-sum
+    differences round apart, against Data.get_cells(trim_zero_exposure=True) source by source
+    and against the oracle's mask; a source whose weights sum to zero keeps its cells."""
+    from godot_amd import core
+    srcs = _ragged_sources()
+    datas = [d for _, d in srcs]
+    datas[3].S = 0.0                       # no source photons expected: sexp = 0 in every cell
+    one = core.get_cells_batch(datas, tcell=600., trim_zero_exposure=True)
+    for k, ((s, d)) in enumerate(srcs):
+        c0, c1 = int(one.cell_offsets[k]), int(one.cell_offsets[k + 1])
+        own = d.get_cells(tcell=600., use_barycenter=False, trim_zero_exposure=True, quiet=True)
+        assert c1 - c0 == len(own) and len(own) > 0
+        for nm in ('starts', 'stops', 'sexp', 'bexp'):
+            a, b = getattr(one.cells, nm)[c0:c1], getattr(own, nm)
+            assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (k, nm)
+        assert torch.equal((one.cells.hi - one.cells.lo)[c0:c1], own.hi - own.lo)
+        b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], d.S, d.B, d.E,
+                          tcell=600.)
+        assert_same(_n(one.cells.starts)[c0:c1], b['starts'], 'starts of the cells the oracle keeps')
+        assert np.array_equal(_n(one.cells.hi - one.cells.lo)[c0:c1], b['counts'])
+
+
 def test_bin_sources_with_dead_time_and_rejected_descriptors():
     """The dead time of every cell equals Data.get_exposure(edges, cumulative=False)'s; a
     descriptor table whose cells overlap, a non-positive cell length and a short workspace

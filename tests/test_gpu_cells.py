@@ -1173,3 +1173,49 @@ def test_dense_team_shapes(mean):
                 continue
             assert np.abs(dom[c] - d).max() <= RTOL * max(1.0, np.abs(d).max()), (c, cnt[c])
             assert np.abs(cod[c] - v).max() <= RTOL * max(sc, np.abs(v).max()), (c, cnt[c])
+
+
+def test_a_slice_of_a_cell_list_is_fitted_with_the_shape_of_its_own_cells():
+    """A thousand daily cells cut out of a ten-year list share the list's weight array, 10^7
+    entries long.  Their photon count travels with them (CellBatch / CellRanges.photons), so
+    the kernels size their shape for 2 700 photons a cell, not for array length / cells =
+    10^4; the results equal the oracle's, and those of the same cells fitted inside the whole
+    list, whichever shape is taken (the shaped entry points change speed only)."""
+    from godot_amd import core, ops, synth
+    DEV = _dev()
+    _n = lambda x: x.cpu().numpy()
+    s = synth.synth(10_000_000, years=10.0, seed=11)
+    data = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=DEV)
+    cells = data.get_cells(tcell=86400., use_barycenter=False, quiet=True)
+    whole = cells.ranges()
+    a_all, t_all, _ = ops.cell_fit(whole)
+    assert cells._photons == whole.photons == int((cells.hi - cells.lo).sum())
+    sub = cells[1500:2500]
+    assert sub.we.numel() == 10_000_000 and len(sub) == 1000
+    cr = sub.ranges()
+    mean = cr.photons / cr.ncell
+    assert 2000 < mean < 3500                    # inherited from the whole list: no device read
+    a, t, fl = ops.cell_fit(cr)
+    assert np.abs(_n(a) - _n(a_all)[1500:2500]).max() <= 1e-12
+    assert np.abs(_n(t) - _n(t_all)[1500:2500]).max() <= 1e-9 * max(1.0, np.abs(_n(t_all)).max())
+    # wrong counts change nothing but the shape: cells taken for tiny, and for huge
+    for fake in (1000 * 3, 1000 * 30000):
+        cr2 = ops.CellRanges(cr.we, cr.lo, cr.hi, cr.S, cr.B, photons=fake)
+        a2, t2, _ = ops.cell_fit(cr2)
+        assert np.abs(_n(a2) - _n(a)).max() <= 1e-12
+        d2, c2, _ = ops.cell_logpdf(ops.CellRanges(cr.we, cr.lo[:50].contiguous(), cr.hi[:50].contiguous(),
+                                                   cr.S[:50].contiguous(), cr.B[:50].contiguous(),
+                                                   photons=fake // 20), dlogl=30, npt=200)
+        d1, c1, _ = ops.cell_logpdf(ops.CellRanges(cr.we, cr.lo[:50].contiguous(), cr.hi[:50].contiguous(),
+                                                   cr.S[:50].contiguous(), cr.B[:50].contiguous()),
+                                    dlogl=30, npt=200)
+        assert np.abs(_n(d2) - _n(d1)).max() <= 1e-9 * np.abs(_n(d1)).max()
+        assert np.abs(_n(c2) - _n(c1)).max() <= 1e-8
+    we, lo, hi = s['we'], _n(cr.lo), _n(cr.hi)
+    S, B = _n(cr.S), _n(cr.B)
+    with np.errstate(all='ignore'):
+        for c in range(0, 1000, 25):
+            cl = orc.CellLike(we[lo[c]:hi[c]], S[c], S[c] / B[c])
+            ar = cl.get_max()
+            assert abs(_n(a)[c] - ar) <= 1e-9 * max(1.0, abs(ar))
+            assert abs(_n(t)[c] - cl.get_ts(ar)) <= 1e-9 * max(-np.log1p(-we[lo[c]:hi[c]]).sum(), 1.0)

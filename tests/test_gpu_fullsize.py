@@ -121,8 +121,8 @@ def test_c2_every_cell_matches_the_oracle(c2):
 
 
 def test_c2_fit_does_not_depend_on_how_the_job_is_split(c2):
-    """Cell ranges fitted on their own (what a rank does, on its own slice of the
-    photons) reproduce the whole job: no cell sees its neighbours.  The kernel
+    """Cell ranges fitted on their own (what a rank does with its share of the cells, over
+    the same weight array) reproduce the whole job: no cell sees its neighbours.  The kernel
     shape follows the shard's occupancy, so sums may be grouped differently:
     agreement to 1e-12, and to the bit for all but a few cells."""
     from godot_amd import ops
@@ -136,8 +136,8 @@ def test_c2_fit_does_not_depend_on_how_the_job_is_split(c2):
         parts = []
         for r in range(world):
             c0, c1 = gd.cell_shard(counts, r, world)
-            sub = cr.shard(c0, c1)
-            assert sub.nph == int(counts[c0:c1].sum()) or sub.nph >= int(counts[c0:c1].sum())
+            sub = cr.shard(c0, c1, photons=int(counts[c0:c1].sum()))
+            assert sub.nph == cr.nph and sub.photons == int(counts[c0:c1].sum())
             parts.append(ops.cell_fit(sub))
         a2 = _n(torch.cat([p[0] for p in parts]))
         t2 = _n(torch.cat([p[1] for p in parts]))
@@ -196,6 +196,47 @@ def test_c4_trig_sums_add_and_match_the_oracle_at_spot_frequencies():
     s2, q2 = ops.z2m_sums(td[cut:].contiguous(), wd[cut:].contiguous(), f0, df, n, m=2, j0=j0)
     zz, _ = ops.z2m_finish(s1 + s2, q1 + q2)
     assert np.abs(_n(zz) - zn[j0:j0 + n]).max() <= 1e-10 * max(1.0, zn[j0:j0 + n].max())
+
+
+def test_c4_search_of_all_trial_frequencies_keeps_the_best_ten():
+    """C4 at full size: 10^6 photons x 10^8 trial frequencies, m = 2, in 48 launches of 2^21
+    frequencies (about half a minute), the global ten best by dist.search_topk_sharded on one
+    rank.  The statistic at those ten frequencies against the oracle's exactly reduced phases;
+    the list is ordered and complete (no value of the spectrum outside it exceeds its last);
+    and two frequency shards, each keeping its own ten best, merge to the same list by the
+    rule the ranks use."""
+    from godot_amd import ops, synth
+    from godot_amd import dist as gd
+    s = synth.synth(1_000_000, years=1.0, seed=17)
+    t, w = s['ti'] - s['ti'][0], s['we']
+    td, wd = torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV)
+    nf, chunk = 100_000_000, 1 << 21
+    f0, df = 1e-4, 1.0 / (4 * float(t[-1]))
+    ws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(td.numel(), chunk, 2), dtype=torch.uint8, device=DEV)
+    zbuf = torch.empty(nf, dtype=torch.float64, device=DEV)
+
+    def search_fn(j0, n):
+        for k0 in range(0, n, chunk):
+            nn = min(chunk, n - k0)
+            zbuf[k0:k0 + nn] = ops.z2m(td, wd, f0, df, nn, m=2, j0=j0 + k0, workspace=ws)[0]
+        return zbuf[:n]
+
+    top_v, top_i = gd.search_topk_sharded(nf, search_fn, k=10)
+    assert len(top_v) == 10 and (np.diff(top_v) <= 0).all() and len(set(top_i.tolist())) == 10
+    for v, j in zip(top_v, top_i):
+        ref = orc.z2m(t, w, f0, df, 1, m=2, j0=int(j))[0]
+        assert abs(v - ref) <= 1e-10 * max(1.0, ref), (j, v, ref)
+    assert int((zbuf > top_v[-1]).sum()) == 9 and float(zbuf.max()) == top_v[0]
+    assert bool(torch.isfinite(zbuf).all()) and float(zbuf.min()) >= 0
+    # two shards: rank r's ten best of its slice, gathered and reduced as search_topk_sharded does
+    rec = []
+    for r in range(2):
+        j0, n = gd.frequency_shard(nf, r, 2)
+        v, i = torch.topk(zbuf[j0:j0 + n], 10)
+        rec.append(np.stack([_n(v), _n(i + j0).astype(np.float64)], axis=1))
+    rec = np.concatenate(rec)
+    order = np.lexsort((rec[:, 1], -rec[:, 0]))[:10]
+    assert np.array_equal(rec[order, 1].astype(np.int64), top_i) and np.array_equal(rec[order, 0], top_v)
 
 
 def test_c3_power_spectrum_matches_numpy_transforms():
