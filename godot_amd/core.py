@@ -605,11 +605,17 @@ class CellLogLikelihood(object):
         return ((W - self.S) * t2 + (N - self.B - W) * t1) / (W2 * t2 - t1 ** 2)
 
 
-def _raise_bad_ranges(flags):
+def _flag_summary(flags):
+    """(any cell with GODOT_F_BAD_RANGE, any cell with GODOT_F_FAILED): ONE read from the device."""
+    both = torch.stack([((flags & 0x80) != 0).any(), ((flags & 0x10) != 0).any()]).cpu()
+    return bool(both[0]), bool(both[1])
+
+
+def _raise_bad_ranges(flags, known=None):
     """A cell whose photon range lies outside the photon arrays (GODOT_F_BAD_RANGE) is a
     fault of whoever built the ranges, never of the data: no allow_failed_cells hides it."""
-    bad = (flags & 0x80) != 0
-    if bool(bad.any().cpu()):
+    if _flag_summary(flags)[0] if known is None else known:
+        bad = (flags & 0x80) != 0
         raise GodotError('photon range of cell %d is not inside the photon arrays'
                          % int(torch.nonzero(bad)[0].cpu()))
 
@@ -620,28 +626,28 @@ def _raise_as_reference(flags, allow):
     a RecursionError when get_logpdf re-centres without end (core.py:923-929).  The
     kernels mark such cells (GODOT_F_FAILED) and go on; with allow=False the batch call
     then raises what the reference would have."""
-    _raise_bad_ranges(flags)
-    if allow:
+    bad_range, failed = _flag_summary(flags)
+    _raise_bad_ranges(flags, bad_range)
+    if allow or not failed:
         return
     bad = (flags & 0x10) != 0
-    if bool(bad.any().cpu()):
-        fl = int(flags[bad][0].cpu())
-        if fl & 0x08:
-            raise ValueError('f(a) and f(b) must have different signs')
-        raise RecursionError('the profile of a cell was re-centred 50 times without agreeing with its maximum')
+    fl = int(flags[bad][0].cpu())
+    if fl & 0x08:
+        raise ValueError('f(a) and f(b) must have different signs')
+    raise RecursionError('the profile of a cell was re-centred 50 times without agreeing with its maximum')
 
 
 def _raise_unconverged_beta(flags, allow, alpha=None):
     """get_beta_max raises a ValueError when its restarts run out (reference core.py:816-819);
     the kernels mark such cells GODOT_F_FAILED and go on."""
-    _raise_bad_ranges(flags)
-    if allow:
+    bad_range, failed = _flag_summary(flags)
+    _raise_bad_ranges(flags, bad_range)
+    if allow or not failed:
         return
     bad = (flags & 0x10) != 0
-    if bool(bad.any().cpu()):
-        i = int(torch.nonzero(bad)[0].cpu())
-        a = '' if alpha is None or not isinstance(alpha, torch.Tensor) else ' for alpha=%.5f' % float(alpha[i].cpu())
-        raise ValueError('Did not converge%s!' % a)
+    i = int(torch.nonzero(bad)[0].cpu())
+    a = '' if alpha is None or not isinstance(alpha, torch.Tensor) else ' for alpha=%.5f' % float(alpha[i].cpu())
+    raise ValueError('Did not converge%s!' % a)
 
 
 class CellsLogLikelihood(object):

@@ -1322,7 +1322,10 @@ extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc
     hipStream_t st = (hipStream_t)stream;
     godot_source_cells *d_src = (godot_source_cells *)workspace;
     Quad *at = (Quad *)((char *)workspace + align256(sizeof(godot_source_cells) * (size_t)nsrc));
-    // pageable host memory: the call returns once the table has been staged, the caller may reuse it
+    // pageable host memory: the call returns once the table has been staged, the caller may reuse
+    // it.  The runtime stages such a copy only after what was queued on the stream before it has
+    // finished, so this call waits for the stream's earlier work (a caller that wants the two
+    // launches queued behind running kernels passes a descriptor table in page-locked memory)
     GODOT_REQUIRE(hipMemcpyAsync(d_src, sources, sizeof(godot_source_cells) * (size_t)nsrc, hipMemcpyHostToDevice,
                                  st) == hipSuccess,
                   GODOT_E_LAUNCH, "godot_bin_sources: copy of the descriptor table failed");

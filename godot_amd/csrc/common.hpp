@@ -74,6 +74,10 @@ __device__ __forceinline__ int dpp_i32(int v)
 // Beyond sixteen lanes the rows' results (every lane of a row holds its row's by then) are
 // read as scalars and combined in the butterfly's own order, (r0 op r1) op (r2 op r3): the
 // same bits as exchanging them through the LDS crossbar (ds_bpermute), without its latency.
+// Preconditions: a one-dimensional workgroup (a team is the aligned lane range
+// threadIdx.x & ~(T - 1) .. + T - 1 of its wavefront), and for T >= 32 every lane of the team
+// active at the call (v_readlane takes rows 0, 16, 32, 48 whether or not they are active; a team
+// that calls with some lanes switched off reads what those lanes held last).
 #define GODOT_TEAM_REDUCE(NAME, TYPE, MOVE, LANE, OP)                    \
     template <int T>                                                     \
     __device__ __forceinline__ TYPE NAME(TYPE v)                         \

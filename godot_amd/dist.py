@@ -77,10 +77,12 @@ def source_shard(nsource, rank=None, world=None, group=None):
 def all_gather_ragged(local, sizes=None, group=None):
     """Concatenate per-rank tensors with different first dimensions, in rank
     order, on every rank.  One all-gather of the sizes, one of the padded
-    records.  (Under the gloo backend the records are gathered on the host.)"""
+    records.  The result lives where `local` does (under the gloo backend the records
+    travel through the host and come back)."""
     rank, world = _world(group)
     if world == 1:
         return local
+    home = local.device
     local = local.to(_device_of(group))
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     if sizes is None:
@@ -94,7 +96,7 @@ def all_gather_ragged(local, sizes=None, group=None):
                       device=local.device)
     dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     out = out.view((world, nmax) + tuple(local.shape[1:]))
-    return torch.cat([out[r, :sizes[r]] for r in range(world)], dim=0)
+    return torch.cat([out[r, :sizes[r]] for r in range(world)], dim=0).to(home)
 
 
 def fit_cells_sharded(counts, fit_fn, group=None):
@@ -247,7 +249,7 @@ def transform_shard(ntransform=5, rank=None, world=None, group=None):
     return list(range(rank, ntransform, min(world, ntransform))) if rank < ntransform else []
 
 
-def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None):
+def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None, device=None):
     """power_spectrum_fft (reference core.py:2683-2741) with its five real transforms of
     length l dealt over the ranks (one whole transform per rank and turn: the spectrum of a
     twelve-year light curve in 100-s bins, l = 2**25, is 268 MB, a single GPU transforms it
@@ -274,7 +276,16 @@ def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None):
         slots = -(-5 // min(world, 5))
         ref = next(iter(parts.values())) if parts else None
         cdev = _device_of(group)                       # where the collective runs (the host under gloo)
-        dev = ref.device if ref is not None else cdev  # where the estimators are formed
+        # where the estimators are formed: the caller's device, that of this rank's own transforms, or
+        # (a rank that owns none, i.e. more than five ranks) the current GPU if there is one
+        if device is not None:
+            dev = torch.device(device)
+        elif ref is not None:
+            dev = ref.device
+        elif torch.cuda.is_available():
+            dev = torch.device('cuda', torch.cuda.current_device())
+        else:
+            dev = cdev
         dtype = ref.dtype if ref is not None else torch.float64
         buf = torch.zeros((slots, nk, 2), dtype=dtype, device=cdev)
         for s_, i in enumerate(mine):

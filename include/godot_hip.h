@@ -317,7 +317,11 @@ typedef struct godot_source_cells {
     const double *ti;        /* time-sorted photon times [nph]                               */
     int64_t n_ft2, nph;
     double s_over_e, b_over_e; /* as for godot_exposure_at; unused with sexposure/bexposure  */
-    double t0, tcell;        /* edge i = i * tcell + t0, i = 0 .. ncell                      */
+    double t0, tcell;        /* edge i = i * tcell + t0, i = 0 .. ncell                      
+ * The descriptor table is copied to the device by the call: from pageable memory that copy
+ * waits for the stream's earlier work, from page-locked memory (hipHostMalloc) it is queued
+ * like the launches.  The grid covers the longest source, so one source with many more cells
+ * than the others launches mostly empty workgroups for them.                  */
     int64_t ncell;
     int64_t cell_offset, photon_offset;
 } godot_source_cells;
