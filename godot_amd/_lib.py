@@ -105,6 +105,9 @@ SIGNATURES = {
     'godot_z2m_sums': (c_int, [c_f64p, c_f64p, c_i64, c_f64, c_f64, c_i64, c_i64, c_int, c_f64p, c_f64p,
                                c_ws, c_size, c_stream]),
     'godot_z2m_finish': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_f64p, c_f64p, c_stream]),
+    'godot_exposure_checkpoints_bytes': (c_size, [c_i64]),
+    'godot_exposure_checkpoints_workspace_bytes': (c_size, [ctypes.c_void_p, c_i64]),
+    'godot_exposure_checkpoints': (c_int, [ctypes.c_void_p, c_i64, c_ws, c_size, c_stream]),
     'godot_exposure_table_rows': (c_int, [c_f64p] * 6 + [c_i64, c_ws, c_size, c_stream]),
     'godot_exposure_at_rows': (c_int, [c_f64p] * 6 + [c_i64, c_ws, c_f64p, c_i64, c_int, c_f64p, c_f64p,
                                                        c_f64p, c_f64p, c_ws, c_size, c_stream]),

@@ -989,6 +989,7 @@ class Data(object):
         else:
             self.E = float(np.sum(np.asarray(exposure, dtype=np.float64)))
         self._exposure_table = None
+        self._checkpoints = None
         self._t0 = float(self.TSTART[0].cpu())
         self._t1 = float(self.TSTOP[-1].cpu())
         # per-row scaled exposures while scalers are applied (reference core.py:2282-2316)
@@ -1055,6 +1056,7 @@ class Data(object):
         self._t0 = float(self.TSTART[0].cpu())
         self._t1 = float(self.TSTOP[-1].cpu())
         self._exposure_table = None
+        self._checkpoints = None
         self._scaled_tables = {}
         self._scaled_key = None
         self._ft2_host = None
@@ -1476,6 +1478,49 @@ def build_exposure_tables(sources, nstream=4):
     return sources
 
 
+def build_exposure_checkpoints(sources, chunk=250):
+    """Compact running sums (ops.exposure_checkpoints: every sixteenth row, 2 bytes a row) for
+    the Data objects that have neither them nor a full table yet, `chunk` sources to a handful
+    of launches.  get_cells_batch and get_timeseries_batch read cells from them with the same
+    bits as from the full tables (80 bytes a row, which a thousand sources over one spacecraft
+    file cannot afford).  Returns `sources`."""
+    todo = [d for d in sources if d._checkpoints is None and d._exposure_table is None]
+    for at in range(0, len(todo), max(1, int(chunk))):
+        part = todo[at:at + max(1, int(chunk))]
+        built = ops.exposure_checkpoints([dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure,
+                                               livetime=d.LIVETIME, s_over_e=d.S / d.E, b_over_e=d.B / d.E)
+                                          for d in part])
+        for d, ck in zip(part, built):
+            d._checkpoints = ck
+    return sources
+
+
+# full tables still to build beyond this many bytes: the compact ones are built instead
+_FULL_TABLES_LIMIT = 4 << 30
+
+
+def _batch_descriptors(sources, spans, compact_tables):
+    """What ops.bin_sources needs of every source, with its exposure table built on the way: the
+    full one where the source has it already (or compact_tables is False), else the compact one."""
+    if compact_tables is None:
+        missing = sum(80 * d.TSTART.numel() for d in sources if d._exposure_table is None)
+        compact_tables = missing > _FULL_TABLES_LIMIT or any(d._checkpoints is not None for d in sources)
+    if compact_tables:
+        build_exposure_checkpoints(sources)
+    else:
+        build_exposure_tables(sources)              # those still to build: over several streams
+    desc = []
+    for d, (t0, t1, tc, nc) in zip(sources, spans):
+        s = dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME, ti=d.ti,
+                 s_over_e=d.S / d.E, b_over_e=d.B / d.E, t0=t0, tcell=tc, ncell=nc)
+        if d._exposure_table is not None:
+            s['table'] = d._exposure_table
+        else:
+            s['checkpoints'] = d._checkpoints
+        desc.append(s)
+    return desc
+
+
 def _kept_per_source(keep, ncl):
     """How many of every source's cells a selection kept: `keep` holds the ascending indices
     of the kept cells, source k owns the ncl[k] cells after those of the sources before it."""
@@ -1519,7 +1564,7 @@ def pack_sources(sources):
 
 
 def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
-                    per_source_calls=False):
+                    per_source_calls=False, compact_tables=None):
     """Data.get_cells(tstart, tstop, tcell, use_barycenter=False) for every Data object of
     `sources`, as one SourceBatch.  Every source is binned on its own edges and exposure
     table, all of them by the same two launches (ops.bin_sources); the zero-exposure cells of
@@ -1527,7 +1572,10 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
     batch, not once per source, and the number of launches does not grow with the number of
     sources (a thousand sources at ten launches each would be bound by issuing them).
     per_source_calls=True, and any source with scalers applied, takes the calls one source
-    at a time instead: the same bits."""
+    at a time instead: the same bits.  compact_tables: True reads the exposures from
+    build_exposure_checkpoints' running sums (2 bytes a table row), False from the full tables
+    (80 bytes a row), None picks the compact ones when the full tables still to build would
+    take more than 4 GiB; the same bits either way."""
     if tcell is None:
         raise ValueError('get_cells_batch needs a cell length')
     if not sources:
@@ -1552,12 +1600,7 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
         source = torch.repeat_interleave(torch.arange(len(per), dtype=I64, device=dev), torch.from_numpy(ncl).to(dev))
         we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
     else:
-        build_exposure_tables(sources)              # those still to build: over several streams
-        desc = []
-        for d, (t0, t1, tc, nc) in zip(sources, spans):
-            desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
-                             table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
-                             t0=t0, tcell=tc, ncell=nc))
+        desc = _batch_descriptors(sources, spans, compact_tables)
         starts, stops, exp, sexp, bexp, _, lo, hi, source = ops.bin_sources(desc)
         ncl = np.array([s['ncell'] for s in desc], dtype=np.int64)
         we, ti = _joined([d.we for d in sources]), _joined([d.ti for d in sources])
@@ -1573,14 +1616,15 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
 
 
-def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True):
+def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
+                         compact_tables=None):
     """Data.get_cells(tstart, tstop, tcell, time_series_only=True, use_barycenter=False) for
     every Data object of `sources` (reference core.py:1958-2206 with the return of 2185-2192):
     a list of CellTimeSeries, one per source, the same bits as the per-source calls.  The
     edges, exposures, dead times and photon ranges of all sources come from the two launches
     of ops.bin_sources, the weight moments of all cells from one more, the trimming from one
     selection: the input of a power spectrum per source (power_spectrum_fft) without a
-    dozen small launches per source."""
+    dozen small launches per source.  compact_tables as for get_cells_batch."""
     if tcell is None:
         raise ValueError('get_timeseries_batch needs a cell length')
     if not sources:
@@ -1593,12 +1637,7 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
     if spans is None:
         return [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
                             time_series_only=True, use_barycenter=False, quiet=quiet) for d in sources]
-    build_exposure_tables(sources)
-    desc = []
-    for d, (t0, t1, tc, nc) in zip(sources, spans):
-        desc.append(dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME,
-                         table=d._plain_exposure_table(), ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E,
-                         t0=t0, tcell=tc, ncell=nc))
+    desc = _batch_descriptors(sources, spans, compact_tables)
     starts, stops, exp, sexp, bexp, dead, lo, hi, source = ops.bin_sources(desc, deadtime_too=True)
     we = _joined([d.we for d in sources])
     w1, w2 = ops.cell_moments(we, lo, hi)

@@ -7,6 +7,7 @@
 #include "common.hpp"
 #include <type_traits>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -415,11 +416,12 @@ __device__ __forceinline__ Quad quad_block_sum(Quad v, Quad *sm)
     return t;
 }
 
-// step 1
-__global__ __launch_bounds__(CS_THREADS) void cs_totals_kernel(ExposureLoad ld, int64_t n, Quad *totals)
+// step 1 (the bodies take the chunk or series a workgroup works on, so that launches over the
+// tables of many sources can call them with blockIdx.y as the source)
+__device__ __forceinline__ void cs_totals_body(const ExposureLoad &ld, int64_t n, Quad *totals, int64_t chunk)
 {
     __shared__ Quad sm[CS_THREADS / WAVE];
-    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK;
+    const int64_t base = chunk * CS_CHUNK;
     Quad v{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < CS_RPT; ++j) {
@@ -427,11 +429,15 @@ __global__ __launch_bounds__(CS_THREADS) void cs_totals_kernel(ExposureLoad ld, 
         if (r < n) v = v + ld(r);
     }
     v = quad_block_sum(v, sm);
-    if (threadIdx.x == 0) totals[blockIdx.x] = v;
+    if (threadIdx.x == 0) totals[chunk] = v;
+}
+__global__ __launch_bounds__(CS_THREADS) void cs_totals_kernel(ExposureLoad ld, int64_t n, Quad *totals)
+{
+    cs_totals_body(ld, n, totals, blockIdx.x);
 }
 
 // step 2: est[c] = sum of totals[0 .. c-1] (one workgroup)
-__global__ __launch_bounds__(1024) void cs_estimate_kernel(const Quad *totals, int64_t nchunk, Quad *est)
+__device__ __forceinline__ void cs_estimate_body(const Quad *totals, int64_t nchunk, Quad *est)
 {
     __shared__ Quad part[1024];
     const int64_t per = (nchunk + 1023) / 1024;
@@ -455,6 +461,10 @@ __global__ __launch_bounds__(1024) void cs_estimate_kernel(const Quad *totals, i
         est[c] = v;
         v = v + totals[c];
     }
+}
+__global__ __launch_bounds__(1024) void cs_estimate_kernel(const Quad *totals, int64_t nchunk, Quad *est)
+{
+    cs_estimate_body(totals, nchunk, est);
 }
 
 // A chunk of the four series in LDS, one padded row of doubles per series: filled
@@ -481,15 +491,15 @@ __device__ __forceinline__ void cs_stage_chunk(const ExposureLoad &ld, int64_t b
 }
 
 // step 3
-__global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, int64_t n, const Quad *est,
-                                                               ChunkInfo *info)
+__device__ __forceinline__ void cs_adders_body(const ExposureLoad &ld, int64_t n, const Quad *est, ChunkInfo *info,
+                                               int64_t chunk)
 {
     __shared__ double s_v[4][CS_PAD];
     __shared__ Adder sm[CS_THREADS];
     __shared__ int sm_flag[2];
     const int tid = threadIdx.x;
-    cs_stage_chunk(ld, (int64_t)blockIdx.x * CS_CHUNK, n, s_v);
-    const Quad e = est[blockIdx.x];
+    cs_stage_chunk(ld, chunk * CS_CHUNK, n, s_v);
+    const Quad e = est[chunk];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const double ec = quad_get(e, c);
@@ -524,18 +534,25 @@ __global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, 
                                  sm[0].even >= 0 && sm[0].odd >= 0;
                 ci = ChunkInfo{sm[0].even, sm[0].odd, k, reg ? 1 : 0};
             }
-            info[(int64_t)blockIdx.x * 4 + c] = ci;
+            info[chunk * 4 + c] = ci;
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(CS_THREADS) void cs_adders_kernel(ExposureLoad ld, int64_t n, const Quad *est,
+                                                               ChunkInfo *info)
+{
+    cs_adders_body(ld, n, est, info, blockIdx.x);
 }
 
 // step 4: blockIdx.x = series.  The exact sum s is carried as its bit pattern:
 // for s in binade k the integer S = s / u is the significand with its leading
 // bit, so entering and leaving a regular chunk is integer work only.
-__global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, int64_t n, int64_t nchunk,
-                                                             const ChunkInfo *info, double *entry, int32_t *by_walk,
-                                                             Quad *cum)
+// COMPACT: cum holds one record per sixteen rows, cum[j] = the sums through row 16 j + 15 (or
+// through the last row of the table): godot_exposure_checkpoints.
+template <bool COMPACT>
+__device__ __forceinline__ void cs_walk_body(const ExposureLoad &ld, int64_t n, int64_t nchunk, const ChunkInfo *info,
+                                             double *entry, int32_t *by_walk, Quad *cum, int col)
 {
     __shared__ ChunkInfo s_info[CS_INFO_TILE];
     __shared__ double s_entry[CS_INFO_TILE];
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
     __shared__ int64_t s_gbits[CS_INFO_TILE / CS_GROUP];
     __shared__ int32_t s_gtaken[CS_INFO_TILE / CS_GROUP];
     constexpr int64_t MANT = ((int64_t)1 << 52) - 1;
-    const int tid = threadIdx.x, col = blockIdx.x;
+    const int tid = threadIdx.x;
     double *cumd = (double *)cum;
     double s = 0.0;                       // thread 0: the exact running sum
     for (int64_t tile0 = 0; tile0 < nchunk; tile0 += CS_INFO_TILE) {
@@ -656,7 +673,10 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
                 s_entry[chunk - tile0] = 0.0;
             }
             __syncthreads();
-            for (int r = tid; r < m; r += CS_THREADS) cumd[(base + r) * 4 + col] = s_x[r];
+            for (int r = tid; r < m; r += CS_THREADS) {
+                if (!COMPACT) cumd[(base + r) * 4 + col] = s_x[r];
+                else if ((r & 15) == 15 || base + r == n - 1) cumd[((base + r) >> 4) * 4 + col] = s_x[r];
+            }
             ++chunk;
             __syncthreads();
         }
@@ -686,21 +706,27 @@ __global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, in
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(CS_THREADS) void cs_walk_kernel(ExposureLoad ld, int64_t n, int64_t nchunk,
+                                                             const ChunkInfo *info, double *entry, int32_t *by_walk,
+                                                             Quad *cum)
+{
+    cs_walk_body<false>(ld, n, nchunk, info, entry, by_walk, cum, blockIdx.x);
+}
 
 // step 5
-__global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, int64_t n, const ChunkInfo *info,
-                                                             const double *entry, const int32_t *by_walk,
-                                                             Quad *cum)
+template <bool COMPACT>
+__device__ __forceinline__ void cs_fill_body(const ExposureLoad &ld, int64_t n, const ChunkInfo *info,
+                                             const double *entry, const int32_t *by_walk, Quad *cum, int64_t chunk)
 {
     __shared__ double s_v[4][CS_PAD];
     __shared__ Adder sm[2][CS_THREADS];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * CS_CHUNK;
+    const int64_t base = chunk * CS_CHUNK;
     cs_stage_chunk(ld, base, n, s_v);
     int done = 0;                                     // series whose sums now stand in s_v
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int64_t ic = (int64_t)blockIdx.x * 4 + c;
+        const int64_t ic = chunk * 4 + c;
         if (by_walk[ic]) continue;                    // uniform over the workgroup
         done |= 1 << c;
         const ChunkInfo in = info[ic];
@@ -745,15 +771,23 @@ __global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, in
     for (int j = 0; j < CS_RPT; ++j) {
         const int r = tid + j * CS_THREADS;
         if (base + r >= n) continue;
+        if (COMPACT && !((r & 15) == 15 || base + r == n - 1)) continue;
+        const int64_t row = COMPACT ? (base + r) >> 4 : base + r;
         const int o = cs_slot(r);
         if (done == 15) {
-            cum[base + r] = Quad{s_v[0][o], s_v[1][o], s_v[2][o], s_v[3][o]};
+            cum[row] = Quad{s_v[0][o], s_v[1][o], s_v[2][o], s_v[3][o]};
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (done & (1 << c)) cumd[(base + r) * 4 + c] = s_v[c][o];
+                if (done & (1 << c)) cumd[row * 4 + c] = s_v[c][o];
         }
     }
+}
+__global__ __launch_bounds__(CS_THREADS) void cs_fill_kernel(ExposureLoad ld, int64_t n, const ChunkInfo *info,
+                                                             const double *entry, const int32_t *by_walk,
+                                                             Quad *cum)
+{
+    cs_fill_body<false>(ld, n, info, entry, by_walk, cum, blockIdx.x);
 }
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -799,15 +833,16 @@ struct UniformEdge {
 
 // cumulative exposures at the query times: core.py:1806-1832.  Called by every thread of a
 // 256-thread workgroup (it synchronises); the workgroup serves queries 256 * blockIdx.x ...
+// The row a query falls in: false for the threads past the last query.
 template <class TimeAt>
-__device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, const Quad *cum, const ExpRow *rows,
-                                                    int64_t n_ft2, const TimeAt times, int64_t n_t, Quad *at)
+__device__ __forceinline__ bool exposure_query_row(const ExposureLoad &ld, int64_t n_ft2, const TimeAt times,
+                                                   int64_t n_t, int64_t &k, double &t, int64_t &idx)
 {
     // sorted queries (cell edges): the rows of the workgroup's first and last query bracket
     // the rows of all the others; those two are searched for by a wavefront each
     __shared__ double s_t[2];
     __shared__ int64_t s_i[2];
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t kb = (int64_t)blockIdx.x * blockDim.x;
     const int64_t kl = (kb + blockDim.x < n_t ? kb + blockDim.x : n_t) - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -828,9 +863,8 @@ __device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, cons
         }
     }
     __syncthreads();
-    if (k >= n_t) return;
-    const double t = times(k);
-    int64_t idx;
+    if (k >= n_t) return false;
+    t = times(k);
     if (s_t[0] <= t && t <= s_t[1]) {
         // The rows of a spacecraft file are evenly spaced but for the gaps: the row is guessed
         // by proportion inside the bracket and the guess and its two neighbours are looked at
@@ -854,13 +888,50 @@ __device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, cons
         idx = lower_bound(ld.tstop, n_ft2, t);   // unsorted queries, NaN
     }
     if (idx >= n_ft2) idx = n_ft2 - 1;   // the reference would index out of range here
-    const ExpRow r = rows[idx];
-    const Quad c = cum[idx];
+    return true;
+}
+// the sums at time t inside row r, whose running sums through the row are c: core.py:1826-1832
+__device__ __forceinline__ Quad exposure_within_row(double t, const ExpRow &r, const Quad &c)
+{
     double frac = __ddiv_rn(__dsub_rn(t, r.t0), __dsub_rn(r.t1, r.t0));
     frac = frac < 0 ? 0.0 : (frac > 1 ? 1.0 : frac);   // np.clip keeps NaN
     frac = 1 - frac;
-    at[k] = Quad{__dsub_rn(c.a, __dmul_rn(r.e, frac)), __dsub_rn(c.b, __dmul_rn(r.se, frac)),
-                 __dsub_rn(c.c, __dmul_rn(r.be, frac)), __dsub_rn(c.d, __dmul_rn(r.dead, frac))};
+    return Quad{__dsub_rn(c.a, __dmul_rn(r.e, frac)), __dsub_rn(c.b, __dmul_rn(r.se, frac)),
+                __dsub_rn(c.c, __dmul_rn(r.be, frac)), __dsub_rn(c.d, __dmul_rn(r.dead, frac))};
+}
+template <class TimeAt>
+__device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, const Quad *cum, const ExpRow *rows,
+                                                    int64_t n_ft2, const TimeAt times, int64_t n_t, Quad *at)
+{
+    int64_t k, idx;
+    double t;
+    if (!exposure_query_row(ld, n_ft2, times, n_t, k, t, idx)) return;
+    at[k] = exposure_within_row(t, rows[idx], cum[idx]);
+}
+
+// The same from the running sums kept for every sixteenth row only (godot_exposure_checkpoints:
+// ck[j] = the sums through row 16 j + 15): the sums through the query's row are the record
+// before its group of sixteen plus the rows of the group up to it, added one after another
+// from the left as numpy.cumsum adds them -- the same roundings, so the same bits as the full
+// table gives, for 2 bytes a row instead of 80.
+constexpr int CK_ROWS = 16;
+__host__ __device__ inline int64_t ck_records(int64_t n) { return (n + CK_ROWS - 1) / CK_ROWS; }
+template <class TimeAt>
+__device__ __forceinline__ void exposure_query_ck_body(const ExposureLoad &ld, const Quad *ck, int64_t n_ft2,
+                                                       const TimeAt times, int64_t n_t, Quad *at)
+{
+    int64_t k, idx;
+    double t;
+    if (!exposure_query_row(ld, n_ft2, times, n_t, k, t, idx)) return;
+    const int64_t j = idx / CK_ROWS;
+    int64_t r = j * CK_ROWS;
+    Quad x = ld(r);
+    Quad c = j > 0 ? ck[j - 1] + x : x;
+    for (++r; r <= idx; ++r) {
+        x = ld(r);
+        c = c + x;
+    }
+    at[k] = exposure_within_row(t, ExpRow{ld.tstart[idx], ld.tstop[idx], x.a, x.b, x.c, x.d}, c);
 }
 
 __global__ __launch_bounds__(256) void exposure_query_kernel(ExposureLoad ld, const Quad *cum,
@@ -1053,9 +1124,71 @@ __global__ __launch_bounds__(256) void sources_query_kernel(const godot_source_c
     const int64_t n_t = s.ncell + 1;
     if (s.ncell <= 0 || (int64_t)blockIdx.x * blockDim.x >= n_t) return;   // the whole workgroup
     ExposureLoad ld{s.tstart, s.tstop, s.exposure, s.livetime, s.s_over_e, s.b_over_e, s.sexposure, s.bexposure};
-    exposure_query_body(ld, (const Quad *)s.table,
-                        (const ExpRow *)((const char *)s.table + table_sums_bytes(s.n_ft2)), s.n_ft2,
-                        UniformEdge{s.t0, s.tcell, 0}, n_t, at + s.cell_offset + k);
+    if (s.checkpoints)   // uniform over the workgroup
+        exposure_query_ck_body(ld, (const Quad *)s.table, s.n_ft2, UniformEdge{s.t0, s.tcell, 0}, n_t,
+                               at + s.cell_offset + k);
+    else
+        exposure_query_body(ld, (const Quad *)s.table,
+                            (const ExpRow *)((const char *)s.table + table_sums_bytes(s.n_ft2)), s.n_ft2,
+                            UniformEdge{s.t0, s.tcell, 0}, n_t, at + s.cell_offset + k);
+}
+
+// Checkpointed running sums of many tables at once (see godot_exposure_checkpoints in the
+// header): the five steps of the parallel running sums above, blockIdx.y = the table.
+struct CkSource {
+    ExposureLoad ld;
+    int64_t n, nchunk;
+    Quad *totals, *est;
+    ChunkInfo *info;
+    double *entry;
+    int32_t *by_walk;
+    Quad *ck;
+};
+__global__ __launch_bounds__(CS_THREADS) void ck_totals_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if ((int64_t)blockIdx.x >= s.nchunk) return;
+    cs_totals_body(s.ld, s.n, s.totals, blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void ck_estimate_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if (s.nchunk == 0) return;
+    cs_estimate_body(s.totals, s.nchunk, s.est);
+}
+__global__ __launch_bounds__(CS_THREADS) void ck_adders_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if ((int64_t)blockIdx.x >= s.nchunk) return;
+    cs_adders_body(s.ld, s.n, s.est, s.info, blockIdx.x);
+}
+__global__ __launch_bounds__(CS_THREADS) void ck_walk_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if (s.nchunk == 0) return;
+    cs_walk_body<true>(s.ld, s.n, s.nchunk, s.info, s.entry, s.by_walk, s.ck, blockIdx.x);
+}
+__global__ __launch_bounds__(CS_THREADS) void ck_fill_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if ((int64_t)blockIdx.x >= s.nchunk) return;
+    cs_fill_body<true>(s.ld, s.n, s.info, s.entry, s.by_walk, s.ck, blockIdx.x);
+}
+// tables too short for the parallel sums: one wavefront a table, lane c walks series c
+__global__ __launch_bounds__(64) void ck_serial_kernel(const CkSource *src)
+{
+    const CkSource &s = src[blockIdx.y];
+    if (s.nchunk > 0) return;   // the parallel steps build this one
+    const int c = threadIdx.x;
+    if (c >= 4) return;
+    double *out = (double *)s.ck;
+    double sum = 0.0;
+    for (int64_t r = 0; r < s.n; ++r) {
+        const Quad x = s.ld(r);
+        const double v = c == 0 ? x.a : (c == 1 ? x.b : (c == 2 ? x.c : x.d));
+        sum = r ? sum + v : v;
+        if ((r & (CK_ROWS - 1)) == CK_ROWS - 1 || r == s.n - 1) out[(r / CK_ROWS) * 4 + c] = sum;
+    }
 }
 
 // Pass two: the photon range of every cell, the exposures between its edges (differences of
@@ -1339,6 +1472,93 @@ extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc
                            out_sexp, out_bexp, out_dead, lo, hi, source);
     }
     GODOT_LAUNCH_CHECK("godot_bin_sources");
+    return GODOT_OK;
+}
+
+extern "C" size_t godot_exposure_checkpoints_bytes(int64_t n_ft2)
+{
+    return n_ft2 <= 0 ? 0 : align256(sizeof(Quad) * (size_t)ck_records(n_ft2));
+}
+
+extern "C" size_t godot_exposure_checkpoints_workspace_bytes(const godot_exposure_rows *tables, int64_t ntab)
+{
+    if (!tables || ntab <= 0) return 0;
+    size_t b = align256(sizeof(CkSource) * (size_t)ntab);
+    for (int64_t k = 0; k < ntab; ++k)
+        if (tables[k].n_ft2 >= 4 * CS_CHUNK) b += cs_scratch_bytes(tables[k].n_ft2);
+    return b;
+}
+
+extern "C" int godot_exposure_checkpoints(const godot_exposure_rows *tables, int64_t ntab, void *workspace,
+                                          size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(ntab >= 0, GODOT_E_INVALID, "godot_exposure_checkpoints: negative number of tables");
+    if (ntab == 0) return GODOT_OK;
+    GODOT_REQUIRE(tables, GODOT_E_INVALID, "godot_exposure_checkpoints: null descriptor table");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_exposure_checkpoints_workspace_bytes(tables, ntab),
+                  GODOT_E_WORKSPACE,
+                  "godot_exposure_checkpoints: workspace smaller than godot_exposure_checkpoints_workspace_bytes");
+    std::vector<CkSource> src((size_t)ntab);
+    char *w = (char *)workspace + align256(sizeof(CkSource) * (size_t)ntab);
+    int64_t max_chunks = 0;
+    bool any_short = false;
+    for (int64_t k = 0; k < ntab; ++k) {
+        const godot_exposure_rows &t = tables[k];
+        GODOT_REQUIRE(t.n_ft2 > 0, GODOT_E_INVALID, "godot_exposure_checkpoints: table %lld: n_ft2 must be positive",
+                      (long long)k);
+        GODOT_REQUIRE(t.tstart && t.tstop && t.exposure && t.livetime && t.checkpoints, GODOT_E_INVALID,
+                      "godot_exposure_checkpoints: table %lld: null pointer", (long long)k);
+        GODOT_REQUIRE((t.sexposure == nullptr) == (t.bexposure == nullptr), GODOT_E_INVALID,
+                      "godot_exposure_checkpoints: table %lld: one rescaled exposure without the other", (long long)k);
+        CkSource &c = src[(size_t)k];
+        c.ld = ExposureLoad{t.tstart, t.tstop, t.exposure, t.livetime, t.s_over_e, t.b_over_e, t.sexposure,
+                            t.bexposure};
+        c.n = t.n_ft2;
+        c.ck = (Quad *)t.checkpoints;
+        c.nchunk = 0;
+        c.totals = c.est = nullptr;
+        c.info = nullptr;
+        c.entry = nullptr;
+        c.by_walk = nullptr;
+        if (t.n_ft2 < 4 * CS_CHUNK) {
+            any_short = true;
+            continue;
+        }
+        const int64_t nc = cs_chunks(t.n_ft2);
+        c.nchunk = nc;
+        c.totals = (Quad *)w;
+        w += align256(sizeof(Quad) * (size_t)nc);
+        c.est = (Quad *)w;
+        w += align256(sizeof(Quad) * (size_t)nc);
+        c.info = (ChunkInfo *)w;
+        w += align256(sizeof(ChunkInfo) * 4 * (size_t)nc);
+        c.entry = (double *)w;
+        w += align256(sizeof(double) * 4 * (size_t)nc);
+        c.by_walk = (int32_t *)w;
+        w += align256(sizeof(int32_t) * 4 * (size_t)nc);
+        if (nc > max_chunks) max_chunks = nc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    CkSource *d_src = (CkSource *)workspace;
+    // pageable host memory: staged before the call returns, after the stream's earlier work
+    GODOT_REQUIRE(hipMemcpyAsync(d_src, src.data(), sizeof(CkSource) * (size_t)ntab, hipMemcpyHostToDevice, st) ==
+                      hipSuccess,
+                  GODOT_E_LAUNCH, "godot_exposure_checkpoints: copy of the descriptor table failed");
+    constexpr int64_t MAX_Y = 65535;
+    for (int64_t first = 0; first < ntab; first += MAX_Y) {
+        const unsigned ny = (unsigned)(ntab - first < MAX_Y ? ntab - first : MAX_Y);
+        const CkSource *d = d_src + first;
+        if (any_short) hipLaunchKernelGGL(ck_serial_kernel, dim3(1, ny), dim3(64), 0, st, d);
+        if (max_chunks == 0) continue;
+        const unsigned nx = (unsigned)max_chunks;
+        hipLaunchKernelGGL(ck_totals_kernel, dim3(nx, ny), dim3(CS_THREADS), 0, st, d);
+        hipLaunchKernelGGL(ck_estimate_kernel, dim3(1, ny), dim3(1024), 0, st, d);
+        hipLaunchKernelGGL(ck_adders_kernel, dim3(nx, ny), dim3(CS_THREADS), 0, st, d);
+        hipLaunchKernelGGL(ck_walk_kernel, dim3(4, ny), dim3(CS_THREADS), 0, st, d);
+        hipLaunchKernelGGL(ck_fill_kernel, dim3(nx, ny), dim3(CS_THREADS), 0, st, d);
+    }
+    GODOT_LAUNCH_CHECK("godot_exposure_checkpoints");
     return GODOT_OK;
 }
 

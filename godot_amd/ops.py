@@ -389,14 +389,75 @@ def bin_photons(ti, start0, stops):
 SOURCE_CELLS = np.dtype([(n, 'u8') for n in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure',
                                              'table', 'ti')]
                         + [('n_ft2', 'i8'), ('nph', 'i8'), ('s_over_e', 'f8'), ('b_over_e', 'f8'), ('t0', 'f8'),
-                           ('tcell', 'f8'), ('ncell', 'i8'), ('cell_offset', 'i8'), ('photon_offset', 'i8')])
+                           ('tcell', 'f8'), ('ncell', 'i8'), ('cell_offset', 'i8'), ('photon_offset', 'i8'),
+                           ('checkpoints', 'i8')])
+# one record per table, field for field the C struct godot_exposure_rows
+EXPOSURE_ROWS = np.dtype([(n, 'u8') for n in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure')]
+                         + [('n_ft2', 'i8'), ('s_over_e', 'f8'), ('b_over_e', 'f8'), ('checkpoints', 'u8')])
+
+
+def _row_pointers(s, k, dev, col):
+    """Checks the exposure-table columns of descriptor `s` and appends their addresses to
+    `col`; returns the number of rows."""
+    n_ft2 = s['tstart'].numel()
+    for nm in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure'):
+        t = s.get(nm)
+        if t is None:
+            if nm in ('sexposure', 'bexposure'):
+                col[nm].append(0)
+                continue
+            raise ValueError('source %d: no %s' % (k, nm))
+        _dev_check(t, F64, nm)
+        if t.numel() != n_ft2 or t.device != dev:
+            raise ValueError('source %d: the exposure table columns must have equal lengths and live on '
+                             'the device of the batch' % k)
+        col[nm].append(t.data_ptr())
+    if (col['sexposure'][-1] == 0) != (col['bexposure'][-1] == 0):
+        raise ValueError('source %d: sexposure and bexposure come together' % k)
+    if n_ft2 < 1:
+        raise ValueError('source %d: empty exposure table' % k)
+    return n_ft2
+
+
+def exposure_checkpoints(tables):
+    """Running sums of many exposure tables, kept for every sixteenth row (2 bytes a row where
+    exposure_table keeps 80), built by launches whose number does not depend on how many tables
+    there are.  `tables`: one dict per table with the device tensors 'tstart', 'tstop',
+    'exposure', 'livetime' (optionally 'sexposure' and 'bexposure') and the numbers 's_over_e',
+    'b_over_e'.  Returns one uint8 tensor per table (views of one allocation) for the
+    'checkpoints' entry of bin_sources' descriptors."""
+    if not tables:
+        return []
+    dev = tables[0]['tstart'].device
+    col = {n: [] for n in EXPOSURE_ROWS.names}
+    sizes = []
+    for k, s in enumerate(tables):
+        n_ft2 = _row_pointers(s, k, dev, col)
+        col['n_ft2'].append(n_ft2)
+        col['s_over_e'].append(float(s.get('s_over_e', 0.0)))
+        col['b_over_e'].append(float(s.get('b_over_e', 0.0)))
+        sizes.append(int(_lib.lib.godot_exposure_checkpoints_bytes(n_ft2)))
+    whole = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    out, at = [], 0
+    for b in sizes:
+        out.append(whole[at:at + b])
+        at += b
+    col['checkpoints'] = [t.data_ptr() for t in out]
+    rec = np.zeros(len(tables), dtype=EXPOSURE_ROWS)
+    for nm in EXPOSURE_ROWS.names:
+        rec[nm] = col[nm]
+    ws = _workspace(_lib.lib.godot_exposure_checkpoints_workspace_bytes(rec.ctypes.data, len(tables)), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_exposure_checkpoints', rec.ctypes.data, len(tables), _p(ws), ws.numel(), _stream(dev))
+    return out
 
 
 def bin_sources(sources, deadtime_too=False):
     """Uniform cells of many sources in two launches.  `sources`: one dict per source with the
     device tensors 'tstart', 'tstop', 'exposure', 'livetime', 'table' (exposure_table of those
-    rows), 'ti' (time-sorted photon times), optionally 'sexposure' and 'bexposure' (with the
-    exposure_table_rows table), and the numbers 's_over_e', 'b_over_e', 't0', 'tcell', 'ncell'.
+    rows) or 'checkpoints' (exposure_checkpoints of them), 'ti' (time-sorted photon times),
+    optionally 'sexposure' and 'bexposure' (with the exposure_table_rows table, or checkpoints
+    built with them), and the numbers 's_over_e', 'b_over_e', 't0', 'tcell', 'ncell'.
     The cells of the sources follow one another in the outputs, and lo/hi index the
     concatenation of the photon lists.  Returns (starts, stops, exp, sexp, bexp, dead or None,
     lo, hi, source) over all cells."""
@@ -406,27 +467,21 @@ def bin_sources(sources, deadtime_too=False):
     col = {n: [] for n in SOURCE_CELLS.names}       # filled column by column: one numpy call a field
     cells = photons = 0
     for k, s in enumerate(sources):
-        n_ft2 = s['tstart'].numel()
-        for nm in ('tstart', 'tstop', 'exposure', 'livetime', 'sexposure', 'bexposure'):
-            t = s.get(nm)
-            if t is None:
-                if nm in ('sexposure', 'bexposure'):
-                    col[nm].append(0)
-                    continue
-                raise ValueError('source %d: no %s' % (k, nm))
-            _dev_check(t, F64, nm)
-            if t.numel() != n_ft2 or t.device != dev:
-                raise ValueError('source %d: the exposure table columns must have equal lengths and live on '
-                                 'the device of the batch' % k)
-            col[nm].append(t.data_ptr())
-        if (col['sexposure'][-1] == 0) != (col['bexposure'][-1] == 0):
-            raise ValueError('source %d: sexposure and bexposure come together' % k)
-        ti, table = s['ti'], s['table']
+        n_ft2 = _row_pointers(s, k, dev, col)
+        ti, table, ck = s['ti'], s.get('table'), s.get('checkpoints')
         _dev_check(ti, F64, 'ti')
         if ti.device != dev:
             raise ValueError('source %d: all sources of a batch live on one device' % k)
-        if table.device != dev or table.numel() < _lib.lib.godot_exposure_table_bytes(n_ft2):
+        if ck is not None:
+            table = ck
+            need = _lib.lib.godot_exposure_checkpoints_bytes(n_ft2)
+        else:
+            need = _lib.lib.godot_exposure_table_bytes(n_ft2)
+        if table is None:
+            raise ValueError("source %d: neither 'table' nor 'checkpoints'" % k)
+        if table.device != dev or table.dtype != torch.uint8 or table.numel() < need:
             raise ValueError('source %d: the table does not belong to these %d rows' % (k, n_ft2))
+        col['checkpoints'].append(int(ck is not None))
         ncell = int(s['ncell'])
         if ncell < 0 or not float(s['tcell']) > 0:
             raise ValueError('source %d: needs ncell >= 0 and tcell > 0' % k)

@@ -309,6 +309,10 @@ int godot_bin_photons(const double *ti, int64_t nph, double start0,
  * before the source); source[...] = k.  The cells of consecutive descriptors
  * must not overlap (cell_offset ascending).  Same bits as the per-source calls
  * godot_exposure_at + godot_bin_photons on the same edges.
+ * The descriptor table is copied to the device by the call: from pageable memory that copy
+ * waits for the stream's earlier work, from page-locked memory (hipHostMalloc) it is queued
+ * like the launches.  The grid covers the longest source, so one source with many more cells
+ * than the others launches mostly empty workgroups for them.
  * workspace: godot_bin_sources_workspace_bytes(nsrc, total_cells).              */
 typedef struct godot_source_cells {
     const double *tstart, *tstop, *exposure, *livetime; /* spacecraft rows [n_ft2]          */
@@ -317,13 +321,10 @@ typedef struct godot_source_cells {
     const double *ti;        /* time-sorted photon times [nph]                               */
     int64_t n_ft2, nph;
     double s_over_e, b_over_e; /* as for godot_exposure_at; unused with sexposure/bexposure  */
-    double t0, tcell;        /* edge i = i * tcell + t0, i = 0 .. ncell                      
- * The descriptor table is copied to the device by the call: from pageable memory that copy
- * waits for the stream's earlier work, from page-locked memory (hipHostMalloc) it is queued
- * like the launches.  The grid covers the longest source, so one source with many more cells
- * than the others launches mostly empty workgroups for them.                  */
+    double t0, tcell;        /* edge i = i * tcell + t0, i = 0 .. ncell                      */
     int64_t ncell;
     int64_t cell_offset, photon_offset;
+    int64_t checkpoints;     /* nonzero: `table` is what godot_exposure_checkpoints wrote     */
 } godot_source_cells;
 size_t godot_bin_sources_workspace_bytes(int64_t nsrc, int64_t total_cells);
 int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc, int64_t total_cells,
@@ -331,6 +332,32 @@ int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc, int64_t t
                       double *out_bexp, double *out_dead, int64_t *lo, int64_t *hi,
                       int64_t *source, void *workspace, size_t workspace_bytes,
                       godot_stream_t stream);
+
+/* Running sums of MANY exposure tables in one call, kept for every sixteenth row
+ * only: record j of a table holds the four sums godot_exposure_table keeps for
+ * every row (exposure, its S/E and B/E multiples, dead time: core.py:1821-1831)
+ * through row 16 j + 15 (the last record through the last row), with numpy.cumsum's
+ * roundings.  A thousand sky positions over one spacecraft file need a thousand
+ * tables; at 80 bytes a row the full tables do not fit beside the photons, at
+ * 2 bytes a row these do.  godot_bin_sources takes them (`checkpoints` nonzero in
+ * the descriptor) and adds the at most fifteen rows between a record and the row
+ * a cell edge falls in, from the left, as the full table was summed: same bits.
+ * `tables` is a HOST array of ntab descriptors with device pointers inside;
+ * `checkpoints` of each: godot_exposure_checkpoints_bytes(n_ft2) bytes, written by
+ * the call.  sexposure/bexposure as in godot_source_cells.  The launch count does
+ * not depend on ntab.  The descriptors are copied to the device by the call (from
+ * pageable memory that copy waits for the stream's earlier work).             */
+typedef struct godot_exposure_rows {
+    const double *tstart, *tstop, *exposure, *livetime; /* spacecraft rows [n_ft2]          */
+    const double *sexposure, *bexposure; /* rescaled per-row exposures (both) or NULL (both) */
+    int64_t n_ft2;
+    double s_over_e, b_over_e;
+    void *checkpoints;
+} godot_exposure_rows;
+size_t godot_exposure_checkpoints_bytes(int64_t n_ft2);
+size_t godot_exposure_checkpoints_workspace_bytes(const godot_exposure_rows *tables, int64_t ntab);
+int godot_exposure_checkpoints(const godot_exposure_rows *tables, int64_t ntab, void *workspace,
+                               size_t workspace_bytes, godot_stream_t stream);
 
 /* The per-photon sums behind the reference's small per-cell functions:
  * log_full_likelihood (core.py:427-438), fmin_tnc_func (440-460), f1/f2/f3

@@ -536,3 +536,128 @@ def test_exposure_tables_built_on_several_streams_are_the_same_tables():
     b = core.get_cells_batch(fresh, tcell=3600.)
     for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp'):
         assert torch.equal(getattr(a.cells, nm).view(torch.int64), getattr(b.cells, nm).view(torch.int64)), nm
+
+
+def _checkpoint_case(case, n, rng):
+    if case == 'realistic':
+        return 27 * (3000 + 2000 * np.sin(np.arange(n) * 0.033) ** 2), np.full(n, 3.0)
+    if case == 'ties':
+        x1 = (2 * rng.integers(0, 1 << 30, n) + 1) * 2.0 ** -14 + 2.0 ** 22
+        x4 = (2 * rng.integers(0, 8, n) + 1) * 2.0 ** -30
+        x4[0] = 2.0 ** 23
+        return x1, x4
+    if case == 'zeros':
+        x1 = np.where(rng.random(n) < 0.7, 0.0, rng.uniform(0, 1e5, n))
+        x1[:min(5000, n // 2)] = 0.0
+        return x1, np.zeros(n)
+    return 10.0 ** rng.uniform(-12, 9, n), 2.0 ** rng.integers(-40, 30, n).astype(np.float64)
+
+
+def test_checkpoints_of_many_tables_are_numpy_cumsum_at_every_sixteenth_row():
+    """godot_exposure_checkpoints builds, for many tables in one call, the running sums that
+    godot_exposure_table builds for one, and keeps those of rows 15, 31, ... and of the last
+    row: numpy.cumsum's bits, for tables whose lengths are and are not multiples of sixteen and
+    of the chunk of the parallel sums, tables too short for the parallel sums among them, and
+    for series that tie at every addition."""
+    from godot_amd import ops
+    rng = np.random.default_rng(77)
+    tables, want = [], []
+    for k, (case, n) in enumerate((('realistic', 150_001), ('ties', 150_000), ('zeros', 40_960), ('range', 8_192),
+                                   ('realistic', 8_191), ('range', 17), ('ties', 16), ('zeros', 1),
+                                   ('ties', 263_000))):
+        x1, x4 = _checkpoint_case(case, n, rng)
+        se, be = 0.173 + 0.01 * k, 0.827 - 0.01 * k
+        z = torch.zeros(n, dtype=torch.float64, device=DEV)
+        tables.append(dict(tstart=z, tstop=torch.from_numpy(x4).to(DEV), exposure=torch.from_numpy(x1).to(DEV),
+                           livetime=z, s_over_e=se, b_over_e=be))
+        with np.errstate(all='ignore'):
+            full = np.stack([np.cumsum(x1), np.cumsum(se * x1), np.cumsum(be * x1), np.cumsum((x4 - 0.0) - 0.0)], 1)
+        rows = np.minimum(np.arange(15, n + 15, 16), n - 1)
+        want.append(full[rows])
+    got = ops.exposure_checkpoints(tables)
+    torch.cuda.synchronize()
+    assert len(got) == len(tables)
+    for k, (g, w) in enumerate(zip(got, want)):
+        g = g[:32 * len(w)].view(torch.float64).view(len(w), 4).cpu().numpy()
+        for c in range(4):
+            assert _same_bits(np.ascontiguousarray(g[:, c]), np.ascontiguousarray(w[:, c])), \
+                (k, c, int(np.argmax(g[:, c] != w[:, c])))
+    assert ops.exposure_checkpoints([]) == []
+
+
+def _ragged_and_short_sources():
+    from godot_amd import core, synth
+    out = _ragged_sources()
+    s = synth.synth(900, years=0.004, seed=499)           # 3 321 rows: the serial sums
+    d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=DEV)
+    out.insert(2, (s, d))
+    return out
+
+
+@pytest.mark.parametrize('tcell', [600., 86400., 3e7])
+def test_cells_read_from_checkpoints_equal_those_read_from_the_full_tables(tcell):
+    """Cells of many sources from the compact running sums (every sixteenth row kept, the rows
+    between added at the query from the left): the bits of the full tables, cell for cell, in
+    every output of godot_bin_sources, for cells shorter and longer than a table row, and in
+    the time series built from them."""
+    from godot_amd import core
+    full = [d for _, d in _ragged_and_short_sources()]
+    compact = [d for _, d in _ragged_and_short_sources()]
+    for trim in (True, False):
+        a = core.get_cells_batch(full, tcell=tcell, trim_zero_exposure=trim, compact_tables=False)
+        b = core.get_cells_batch(compact, tcell=tcell, trim_zero_exposure=trim, compact_tables=True)
+        assert np.array_equal(a.cell_offsets, b.cell_offsets)
+        assert torch.equal(a.source, b.source)
+        for nm in ('lo', 'hi', 'starts', 'stops', 'sexp', 'bexp'):
+            x, y = getattr(a.cells, nm), getattr(b.cells, nm)
+            assert x.shape == y.shape and torch.equal(x.view(torch.int64), y.view(torch.int64)), nm
+    assert all(d._checkpoints is not None and d._exposure_table is None for d in compact)
+    assert all(d._checkpoints is None and d._exposure_table is not None for d in full)
+    n = full[0].TSTART.numel()
+    assert compact[0]._checkpoints.numel() <= 2 * n + 256 < 80 * n <= full[0]._exposure_table.numel()
+    ta = core.get_timeseries_batch(full, tcell=tcell)
+    tb = core.get_timeseries_batch(compact, tcell=tcell)           # picks the tables the sources have
+    for x, y in zip(ta, tb):
+        for nm in core.CellTimeSeries._KEYS:
+            u, v = getattr(x, nm), getattr(y, nm)
+            assert u.shape == v.shape and torch.equal(u.view(torch.int64), v.view(torch.int64)), nm
+    # first source against the oracle
+    s, d = _ragged_and_short_sources()[0]
+    got = core.get_cells_batch(compact, tcell=tcell)
+    b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], d.S, d.B, d.E,
+                      tcell=tcell)
+    c0, c1 = int(got.cell_offsets[0]), int(got.cell_offsets[1])
+    assert c1 - c0 == len(b['counts'])
+    assert np.array_equal(_n(got.cells.hi - got.cells.lo)[c0:c1], b['counts'])
+    assert_same(_n(got.cells.sexp)[c0:c1], b['sexp'], "b['sexp']")
+    assert_same(_n(got.cells.bexp)[c0:c1], b['bexp'], "b['bexp']")
+
+
+def test_checkpoints_of_rescaled_exposure_rows():
+    """Checkpoints built from per-row source and background exposures give godot_bin_sources
+    the bits of the godot_exposure_table_rows table."""
+    from godot_amd import ops
+    (s0, d0), (s1, d1) = _ragged_sources()[:3:2]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(6)
+    n = d0.exposure.numel()
+    sexposure = (d0.exposure * (d0.S / d0.E) * (0.5 + torch.rand(n, dtype=torch.float64, device=DEV, generator=g))).contiguous()
+    bexposure = (d0.exposure * (d0.B / d0.E) * (0.5 + torch.rand(n, dtype=torch.float64, device=DEV, generator=g))).contiguous()
+    table = ops.exposure_table_rows(d0.TSTART, d0.TSTOP, d0.exposure, sexposure, bexposure, d0.LIVETIME)
+    rows = [dict(tstart=d0.TSTART, tstop=d0.TSTOP, exposure=d0.exposure, livetime=d0.LIVETIME, sexposure=sexposure,
+                 bexposure=bexposure),
+            dict(tstart=d1.TSTART, tstop=d1.TSTOP, exposure=d1.exposure, livetime=d1.LIVETIME, s_over_e=d1.S / d1.E,
+                 b_over_e=d1.B / d1.E)]
+    cks = ops.exposure_checkpoints(rows)
+    outs = []
+    for tabs in ((dict(table=table), dict(table=d1._plain_exposure_table())),
+                 (dict(checkpoints=cks[0]), dict(checkpoints=cks[1]))):
+        desc = []
+        for d, r, tab in zip((d0, d1), rows, tabs):
+            t0, t1, tc, nc = d._uniform_cells(None, None, 5400., True)
+            desc.append(dict(r, ti=d.ti, s_over_e=d.S / d.E, b_over_e=d.B / d.E, t0=t0, tcell=tc, ncell=nc, **tab))
+        outs.append(ops.bin_sources(desc, deadtime_too=True))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    with pytest.raises(ValueError):
+        ops.bin_sources([dict(desc[0], checkpoints=cks[0][:100])])
