@@ -295,13 +295,15 @@ class CellTimeSeries(object):
                               timesys=timesys, minimum_exposure=minimum_exposure)
 
     def tsamp(self):
-        return float(self.stops[0] - self.starts[0])
+        known = getattr(self, '_tsamp', None)       # set by builders that know the edges on the host
+        return float(self.stops[0] - self.starts[0]) if known is None else known
 
     def ps_nbin(self):
         return len(self.starts) // 4 + 1
 
     def tspan(self):
-        return float(self.stops[-1] - self.starts[0])
+        known = getattr(self, '_tspan', None)
+        return float(self.stops[-1] - self.starts[0]) if known is None else known
 
     def get_topo_bins(self):
         if self.timesys == 'barycenter':
@@ -1662,8 +1664,62 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
         ts.alt_starts = ts.alt_stops = None
         ts.timesys = 'topocentric'
         ts.minimum_exposure = 0
+        if not trim_zero_exposure:
+            # untrimmed: the first and last edges are those of the span, edge i = i * tcell + t0
+            # rounded as the kernels (and numpy) round it; no device read for tsamp() / tspan()
+            t0, _, tc, nc = spans[k]
+            ts._tsamp = (1.0 * tc + t0) - (0.0 * tc + t0)
+            ts._tspan = (float(nc) * tc + t0) - (0.0 * tc + t0)
         out.append(ts)
     return out
+
+
+class SourceResults(object):
+    """What run_sources returns.  batch: the SourceBatch of the fitted cells; alpha, ts, flags:
+    ops.cell_fit's per-cell results for all sources (batch.split cuts them per source);
+    peak_power[k, j], peak_freq[k, j]: the largest value of source k's spectrum j (P_0, P_1,
+    P_b of power_spectrum_fft) above zero frequency and the frequency [Hz] it stands at;
+    spectra: per source (l, tsamp, P_0, P_1, P_b) with device tensors when asked for, else
+    None."""
+
+    def __init__(self, batch, alpha, ts, flags, peak_power, peak_freq, spectra):
+        self.batch, self.alpha, self.ts, self.flags = batch, alpha, ts, flags
+        self.peak_power, self.peak_freq, self.spectra = peak_power, peak_freq, spectra
+
+
+def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32, dfgoal=None,
+                keep_spectra=False, compact_tables=None):
+    """Many sources as one job: for every Data object the cells of length tcell_fit fitted
+    (Data.get_cells + the per-cell maximisation of CellsLogLikelihood, reference
+    core.py:1958, 1070) and the power spectra of its time series of tcell_ps bins
+    (get_cells(time_series_only=True) + power_spectrum_fft, core.py:2598).  The exposure
+    tables of all sources are built by a handful of launches, the cells of all sources are
+    binned by two and fitted by one; the time series are binned `chunk` sources at a time
+    (a source's series at 300-s bins is 10^6 bins of nine columns) and transformed one source
+    after another.  The host reads results back once, at the end."""
+    if not sources:
+        raise ValueError('no sources')
+    batch = get_cells_batch(sources, tstart=tstart, tstop=tstop, tcell=tcell_fit, compact_tables=compact_tables)
+    alpha, ts_, flags = ops.cell_fit(batch.cells.ranges())
+    peaks, df, spectra = [], [], ([] if keep_spectra else None)
+    chunk = max(1, int(chunk))
+    for at in range(0, len(sources), chunk):
+        series = get_timeseries_batch(sources[at:at + chunk], tstart=tstart, tstop=tstop, tcell=tcell_ps,
+                                      trim_zero_exposure=False, compact_tables=compact_tables)
+        for ser in series:
+            l, tsamp, p0, p1, pb, _ = _power_spectrum_parts(ser, dfgoal=dfgoal)
+            v = [torch.max(p[1:], 0) for p in (p0, p1, pb)]
+            peaks.append(torch.stack([torch.stack([m.values for m in v]),
+                                      torch.stack([m.indices for m in v]).to(F64)]))
+            df.append((1.0 / l, tsamp))
+            if keep_spectra:
+                spectra.append((l, tsamp, p0, p1, pb))
+        del series
+    pk = torch.stack(peaks).cpu().numpy()           # the one read of the job
+    df = np.array(df)
+    # bin i stands at (i * (1 / l)) / tsamp, as power_spectrum_fft forms its frequencies
+    freq = ((pk[:, 1] + 1) * df[:, :1]) / df[:, 1:]
+    return SourceResults(batch, alpha, ts_, flags, pk[:, 0], freq, spectra)
 
 
 class PhaseData(object):
@@ -1732,11 +1788,10 @@ def _ts_dev(ts, name, dev):
     return _to_dev(getattr(ts, name), dev)
 
 
-def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False, get_amps=False,
-                       exposure_correction=None, no_zero_pad=False, maxN=None, device=None):
-    """FFT evaluation of the first-order likelihood power spectra.  Returns
-    (frequencies [Hz], P_0, P_1, P_b) as numpy arrays, or the amplitude tuple
-    of get_amps=True, exactly as the reference orders them."""
+def _power_spectrum_parts(timeseries, dfgoal=None, tweak_exp=False, exp_only=False, get_amps=False,
+                          exposure_correction=None, no_zero_pad=False, maxN=None, device=None):
+    """power_spectrum_fft without the trip to the host: (l, tsamp, P_0, P_1, P_b, amplitudes)
+    with the spectra as device tensors of l // 4 + 1 bins."""
     cells = timeseries
     dev = device or (cells.weights.device if isinstance(cells.weights, torch.Tensor)
                      else default_device())
@@ -1760,20 +1815,32 @@ def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False,
     if exp_only:
         W = 2 * S - S.mean()
 
+    tsamp = cells.tsamp()
     if dfgoal is None:
         dfgoal = 0.2 / cells.tspan()
-    nfft = 1. / (cells.tsamp() * dfgoal)
+    nfft = 1. / (tsamp * dfgoal)
     l = 2 ** (int(np.log2(nfft)) + 1)
     if no_zero_pad:
         l = W.numel()
     if l < W.numel():
         raise NotImplementedError('dfgoal gives a transform shorter than the series')
-    # np.fft.rfftfreq(l) / tsamp cut to l // 4 + 1 bins (core.py:2679) without forming the other half of
-    # rfftfreq's array: the same products and quotients, element for element
-    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) / cells.tsamp()
     p0, p1, pb, amps = ops.power_spectrum_fft(W.contiguous(), WW.contiguous(), S.contiguous(),
                                               Wb.contiguous(), WbWb.contiguous(), B.contiguous(),
                                               l, want_amps=get_amps)
+    return l, tsamp, p0, p1, pb, amps
+
+
+def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False, get_amps=False,
+                       exposure_correction=None, no_zero_pad=False, maxN=None, device=None):
+    """FFT evaluation of the first-order likelihood power spectra.  Returns
+    (frequencies [Hz], P_0, P_1, P_b) as numpy arrays, or the amplitude tuple
+    of get_amps=True, exactly as the reference orders them."""
+    l, tsamp, p0, p1, pb, amps = _power_spectrum_parts(
+        timeseries, dfgoal=dfgoal, tweak_exp=tweak_exp, exp_only=exp_only, get_amps=get_amps,
+        exposure_correction=exposure_correction, no_zero_pad=no_zero_pad, maxN=maxN, device=device)
+    # np.fft.rfftfreq(l) / tsamp cut to l // 4 + 1 bins (core.py:2679) without forming the other half of
+    # rfftfreq's array: the same products and quotients, element for element
+    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) / tsamp
     if get_amps:
         a = _np(amps)
         return (freqs,) + tuple(a[i] for i in range(8))

@@ -312,6 +312,72 @@ def test_multi_source_batch_matches_the_oracle_cell_for_cell():
             assert np.allclose(got, pieces[k], rtol=1e-12, atol=0, equal_nan=True)
 
 
+def test_run_sources_fits_and_spectra_match_the_oracle_source_by_source():
+    """The multi-source job through its driver (core.run_sources: compact exposure tables of all
+    sources, cells of all sources binned and fitted together, time series binned in chunks,
+    one power spectrum per source), four sources of 2e5 photons over two years: every daily
+    cell's maximum and TS against the oracle's get_max / get_ts, and every source's P_0, P_1,
+    P_b at 300-s bins against the oracle's own binning (bin_cells, zero_low_exposure) and its
+    five numpy transforms (power_spectrum_fft), peak and peak frequency included."""
+    from godot_amd import core, synth
+    dev = torch.device('cuda:0')
+    nsrc = 4
+    raw = [synth.synth(200_000, years=2.0, seed=1000 + k) for k in range(nsrc)]
+    for k, s in enumerate(raw):
+        s['S'] *= 1.0 + 0.1 * k
+    datas = []
+    for s in raw:
+        d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=dev)
+        d.S, d.B = s['S'], s['B']
+        datas.append(d)
+    res = core.run_sources(datas, tcell_fit=86400., tcell_ps=300., chunk=3, keep_spectra=True, compact_tables=True)
+    assert all(d._exposure_table is None and d._checkpoints is not None for d in datas)
+    assert len(res.batch) == nsrc and len(res.spectra) == nsrc
+    assert not (res.flags.cpu().numpy() & 0x10).any()
+    alpha, ts = res.alpha.cpu().numpy(), res.ts.cpu().numpy()
+    with np.errstate(all='ignore'):
+        for k, s in enumerate(raw):
+            # the fit half
+            b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], s['S'],
+                              s['B'], s['E'], tcell=86400.)
+            c0, c1 = int(res.batch.cell_offsets[k]), int(res.batch.cell_offsets[k + 1])
+            assert c1 - c0 == len(b['counts']) > 700
+            for i, cl in enumerate(orc.cells_from_bins(b)):
+                a = cl.get_max()
+                t = cl.get_ts(a)
+                sc = max(1.0, np.abs(np.log1p(-cl.we)).sum())
+                assert abs(alpha[c0 + i] - a) <= 1e-9 * max(1, abs(a)), (k, i, alpha[c0 + i], a)
+                assert abs(ts[c0 + i] - t) <= 1e-9 * max(sc, abs(t)), (k, i, ts[c0 + i], t)
+            # the periodogram half
+            b = orc.bin_cells(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['exposure'], s['LIVETIME'], s['S'],
+                              s['B'], s['E'], tcell=300., trim_zero_exposure=False)
+            b['counts'] = b['counts'].astype(np.float64)
+            orc.zero_low_exposure(b, 0)
+            rf, r0, r1, rb = orc.power_spectrum_fft(b['starts'], b['stops'], b['counts'], b['wsum'], b['w2sum'],
+                                                    b['sexp'], b['bexp'])
+            l, tsamp, p0, p1, pb = res.spectra[k]
+            assert l == 2 * (len(rf) - 1) * 2 and tsamp == b['stops'][0] - b['starts'][0]
+            for j, (got, ref, nm) in enumerate(((p0, r0, 'P0'), (p1, r1, 'P1'), (pb, rb, 'Pb'))):
+                got = got.cpu().numpy()
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(got), fin), (k, nm)
+                tol = RTOL * np.maximum(np.abs(ref[fin]), 1e-3 * np.abs(ref[fin]).max())
+                assert (np.abs(got[fin] - ref[fin]) <= tol).all(), (k, nm, np.abs(got[fin] - ref[fin]).max())
+                at = 1 + int(np.nanargmax(ref[1:]))
+                assert abs(res.peak_power[k, j] - ref[at]) <= 1e-9 * abs(ref[at]), (k, nm)
+                assert res.peak_freq[k, j] == rf[at], (k, nm, res.peak_freq[k, j], rf[at])
+    # the same job without keeping the spectra, full tables, one source a chunk: the same summaries
+    fresh = []
+    for s in raw:
+        d = core.Data(s['ti'], s['we'], s['TSTART'], s['TSTOP'], s['LIVETIME'], s['exposure'], device=dev)
+        d.S, d.B = s['S'], s['B']
+        fresh.append(d)
+    res2 = core.run_sources(fresh, tcell_fit=86400., tcell_ps=300., chunk=1, compact_tables=False)
+    assert res2.spectra is None and all(d._exposure_table is not None for d in fresh)
+    assert np.array_equal(res2.peak_power, res.peak_power) and np.array_equal(res2.peak_freq, res.peak_freq)
+    assert torch.equal(res2.alpha, res.alpha)
+
+
 def test_c1_raw_light_curve_at_full_size():
     """C1 as stated: 1e6 photons (seed 7), ten years, one-day cells; binning, profiles and the
     raw light curve of all 3 652 cells against the oracle."""
