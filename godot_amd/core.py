@@ -12,6 +12,7 @@ and per-cell ``starts, stops, sexp, bexp``.  ``Cell`` objects (the
 reference's per-cell value type, core.py:161-187) are materialised from a
 batch only on request.
 """
+import time
 import numpy as np
 import torch
 
@@ -1501,16 +1502,23 @@ def build_exposure_checkpoints(sources, chunk=250):
 _FULL_TABLES_LIMIT = 4 << 30
 
 
-def _batch_descriptors(sources, spans, compact_tables):
-    """What ops.bin_sources needs of every source, with its exposure table built on the way: the
-    full one where the source has it already (or compact_tables is False), else the compact one."""
+def _batch_tables(sources, compact_tables):
+    """Builds the exposure tables the sources still lack: compact ones if asked for, or (None)
+    if full ones would take more than _FULL_TABLES_LIMIT bytes or some source has compact ones."""
     if compact_tables is None:
         missing = sum(80 * d.TSTART.numel() for d in sources if d._exposure_table is None)
         compact_tables = missing > _FULL_TABLES_LIMIT or any(d._checkpoints is not None for d in sources)
     if compact_tables:
         build_exposure_checkpoints(sources)
     else:
-        build_exposure_tables(sources)              # those still to build: over several streams
+        build_exposure_tables(sources)              # over several streams
+    return sources
+
+
+def _batch_descriptors(sources, spans, compact_tables):
+    """What ops.bin_sources needs of every source, with its exposure table built on the way: the
+    full one where the source has it already (or compact_tables is False), else the compact one."""
+    _batch_tables(sources, compact_tables)
     desc = []
     for d, (t0, t1, tc, nc) in zip(sources, spans):
         s = dict(tstart=d.TSTART, tstop=d.TSTOP, exposure=d.exposure, livetime=d.LIVETIME, ti=d.ti,
@@ -1688,7 +1696,7 @@ class SourceResults(object):
 
 
 def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32, dfgoal=None,
-                keep_spectra=False, compact_tables=None):
+                keep_spectra=False, compact_tables=None, timings=None):
     """Many sources as one job: for every Data object the cells of length tcell_fit fitted
     (Data.get_cells + the per-cell maximisation of CellsLogLikelihood, reference
     core.py:1958, 1070) and the power spectra of its time series of tcell_ps bins
@@ -1696,16 +1704,32 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
     tables of all sources are built by a handful of launches, the cells of all sources are
     binned by two and fitted by one; the time series are binned `chunk` sources at a time
     (a source's series at 300-s bins is 10^6 bins of nine columns) and transformed one source
-    after another.  The host reads results back once, at the end."""
+    after another.  The host reads results back once, at the end.  `timings`: a dict that
+    receives the seconds spent per stage (the device is then waited for after every stage)."""
     if not sources:
         raise ValueError('no sources')
+    dev = sources[0].device
+    clock = [time.perf_counter()]
+
+    def lap(stage):
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            timings[stage] = timings.get(stage, 0.0) + now - clock[0]
+            clock[0] = now
+
+    _batch_tables(sources, compact_tables)
+    lap('exposure_tables')
     batch = get_cells_batch(sources, tstart=tstart, tstop=tstop, tcell=tcell_fit, compact_tables=compact_tables)
+    lap('cells')
     alpha, ts_, flags = ops.cell_fit(batch.cells.ranges())
+    lap('fit')
     peaks, df, spectra = [], [], ([] if keep_spectra else None)
     chunk = max(1, int(chunk))
     for at in range(0, len(sources), chunk):
         series = get_timeseries_batch(sources[at:at + chunk], tstart=tstart, tstop=tstop, tcell=tcell_ps,
                                       trim_zero_exposure=False, compact_tables=compact_tables)
+        lap('time_series')
         for ser in series:
             l, tsamp, p0, p1, pb, _ = _power_spectrum_parts(ser, dfgoal=dfgoal)
             v = [torch.max(p[1:], 0) for p in (p0, p1, pb)]
@@ -1715,7 +1739,9 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
             if keep_spectra:
                 spectra.append((l, tsamp, p0, p1, pb))
         del series
+        lap('spectra')
     pk = torch.stack(peaks).cpu().numpy()           # the one read of the job
+    lap('read_back')
     df = np.array(df)
     # bin i stands at (i * (1 / l)) / tsamp, as power_spectrum_fft forms its frequencies
     freq = ((pk[:, 1] + 1) * df[:, :1]) / df[:, 1:]

@@ -28,3 +28,30 @@ def synth(nph, years=10., seed=7):
     B = len(we) - S
     return dict(ti=ti, we=we, TSTART=TSTART, TSTOP=TSTOP, LIVETIME=LIVETIME,
                 exposure=exposure, S=S, B=B, E=E)
+
+
+def synth_sources_device(nsrc, device, nph=1_000_000, years=10., seed=1000):
+    """Many sources over ONE spacecraft file, made on the GPU (a thousand host-made sources
+    take minutes): TSTART, TSTOP, LIVETIME as synth() makes them, shared by all sources; every
+    source has its own exposure column (that of synth() times 1 + k / 1000: its own sky
+    position), photons drawn in proportion to exposure (uniform inside their row) and weights
+    clip(u^3.3, 1e-6, 1 - 1e-6), u uniform: mostly background with a tail of source photons,
+    like the Beta(0.3, 1.5) of synth().  Returns a list of dicts of device tensors with the
+    keys of synth() (without the totals)."""
+    import torch
+    base = synth(1, years=years, seed=seed)
+    TSTART, TSTOP, LIVETIME, exposure = [torch.from_numpy(base[k]).to(device)
+                                         for k in ('TSTART', 'TSTOP', 'LIVETIME', 'exposure')]
+    cdf = torch.cumsum(exposure, 0)
+    cdf = cdf / cdf[-1]
+    g = torch.Generator(device=device)
+    out = []
+    for k in range(nsrc):
+        g.manual_seed(seed + k)
+        u = lambda: torch.rand(nph, dtype=torch.float64, device=device, generator=g)
+        idx = torch.searchsorted(cdf, u()).clamp_(max=cdf.numel() - 1)
+        ti = torch.sort(TSTART[idx] + 30 * u())[0]
+        we = u().pow_(3.3).clamp_(1e-6, 1 - 1e-6)
+        out.append(dict(ti=ti, we=we, TSTART=TSTART, TSTOP=TSTOP, LIVETIME=LIVETIME,
+                        exposure=exposure * (1.0 + 0.001 * k)))
+    return out
