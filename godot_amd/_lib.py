@@ -57,6 +57,8 @@ SIGNATURES = {
                                            c_int, c_f64p, c_f64p, c_i32p, c_stream]),
     'godot_profile_quantiles': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_f64, c_f64, c_f64p, c_f64p,
                                         c_f64p, c_stream]),
+    'godot_profile_quantiles_linspace': (c_int, [c_f64p, c_f64p, c_i64, c_int, c_f64, c_f64, c_f64p, c_f64p,
+                                        c_f64p, c_stream]),
     'godot_lightcurve_rows': (c_int, [c_f64p] * 7 + [c_i64, c_f64, c_f64p, c_stream]),
     'godot_met2mjd': (c_int, [c_f64p, c_i64, c_f64, c_f64p, c_stream]),
     'godot_cell_beta_max': (c_int, _CELLS + [c_f64p, c_f64p, c_i64, c_f64p, c_f64, c_f64p, c_f64,

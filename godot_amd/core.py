@@ -683,8 +683,12 @@ class CellsLogLikelihood(object):
             self._dom_d, self._cod_d, self._flags = ops.cell_logpdf(self._cr, dlogl=30, npt=200,
                                                                     swap=self._swap)
             _raise_as_reference(self._flags, self.allow_failed_cells)
+        # the rows of _dom_d are what the kernels wrote: numpy.linspace of their ends, to the bit
+        self._rows_linspace = True
         self._dom_h = self._cod_h = None
         self.fitness_vals = None
+
+    _rows_linspace = False
 
     @property
     def _dom(self):
@@ -720,7 +724,8 @@ class CellsLogLikelihood(object):
 
     def get_flux_all(self, conf=[0.05, 0.95]):
         """(aopt, ts, xlo, xhi) device tensors for every cell."""
-        ag, xlo, xhi = ops.profile_quantiles(self._dom_d, self._cod_d, conf[0], conf[1])
+        ag, xlo, xhi = ops.profile_quantiles(self._dom_d, self._cod_d, conf[0], conf[1],
+                                             linspace=self._rows_linspace)
         if self.profile_background:
             # core.py:1231-1245: beta guess from the profile, joint refit, profile TS
             bg, _, bf = ops.cell_beta_max(self._cr, ag, swap=self._swap, want_logl=False)
@@ -748,6 +753,7 @@ class CellsLogLikelihood(object):
                                  self._cr.B[idx:idx + 1].contiguous())
         sub._dom_d = self._dom_d[idx:idx + 1].contiguous()
         sub._cod_d = self._cod_d[idx:idx + 1].contiguous()
+        sub._rows_linspace = self._rows_linspace
         sub._swap = self._swap
         sub.profile_background = self.profile_background
         sub.allow_failed_cells = self.allow_failed_cells
@@ -840,7 +846,7 @@ class CellsLogLikelihood(object):
             if bool((fl & 0x10).any().cpu()):
                 raise ValueError('f(a) and f(b) must have different signs')
             dom, cod, _ = ops.cell_logpdf(cr, aopt=aopt, dlogl=20, npt=100, swap=self._swap)
-        ag, xlo, xhi = ops.profile_quantiles(dom, cod, 0.16, 0.84)
+        ag, xlo, xhi = ops.profile_quantiles(dom, cod, 0.16, 0.84, linspace=True)
         aopt, ts, xlo, xhi = _np(aopt), _np(ts), _np(xlo), _np(xhi)
         for b in np.flatnonzero(np.abs(_np(ag) - aopt) > 0.1):
             cl = CellLogLikelihood(blocks[int(b)], swap=self._swap, device=blocks.device)

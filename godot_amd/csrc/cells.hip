@@ -554,6 +554,10 @@ __global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *do
 // keeps points 4l .. 4l+3 in registers, adds its own trapezoids serially and the wavefront
 // scans the 64 lane totals once, where the kernel above scans every chunk of 64 points and
 // stages the row in LDS.  Same results up to the order of the additions.
+// LINSPACE: the abscissae of a row are numpy.linspace(first, last, npt) of its ends to the bit
+// (what the profile kernels write): only the two ends are read, the row's abscissae are formed
+// as those kernels form them, and the kernel moves half the bytes.
+template <bool LINSPACE>
 __global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *dom, const double *cod,
                                                                  int64_t ncell, int npt, double c_lo,
                                                                  double c_hi, double *aguess,
@@ -569,31 +573,47 @@ __global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *d
     double d[5], pdf[5];
     double best = -INFINITY;
     int ibest = npt;
+    double first = 0.0, last = 0.0, step = 0.0;
+    if (LINSPACE) {
+        first = dp[0];
+        last = dp[npt - 1];
+        step = (last - first) / (double)(npt - 1);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = i0 + k;
         const bool in = i < npt;
         const int ii = in ? i : npt - 1;
         const double v = cp[ii];
-        d[k] = dp[ii];
+        d[k] = LINSPACE ? grid_point(first, last, step, ii, npt) : dp[ii];
         pdf[k] = in ? exp(v) : 0.0;
         if (in && v > best) {
             best = v;
             ibest = i;
         }
     }
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, WAVE);
-        const int oi = __shfl_xor(ibest, o, WAVE);
-        if (ob > best || (ob == best && oi < ibest)) {
-            best = ob;
-            ibest = oi;
+    // the first maximum of the row: the largest value, then the smallest index that holds it
+    // (DPP reductions; a NaN is never a lane's best)
+    {
+        const double gbest = team_max<WAVE>(best);
+        ibest = team_min_i32<WAVE>(best == gbest ? ibest : npt);
+    }
+    // point 4l+4 belongs to the next lane: the neighbour inside a row of sixteen lanes by DPP,
+    // across the rows' ends through the scalar unit
+    {
+        const int row = lane >> 4;
+        const double p16 = lane_f64(pdf[0], 16), p32 = lane_f64(pdf[0], 32), p48 = lane_f64(pdf[0], 48);
+        pdf[4] = dpp_f64<0x101>(pdf[0]);                       // row_shl:1
+        if ((lane & 15) == 15) pdf[4] = row == 0 ? p16 : (row == 1 ? p32 : p48);
+        if (LINSPACE) {
+            const int i4 = i0 + 4 < npt ? i0 + 4 : npt - 1;
+            d[4] = grid_point(first, last, step, i4, npt);
+        } else {
+            const double d16 = lane_f64(d[0], 16), d32 = lane_f64(d[0], 32), d48 = lane_f64(d[0], 48);
+            d[4] = dpp_f64<0x101>(d[0]);
+            if ((lane & 15) == 15) d[4] = row == 0 ? d16 : (row == 1 ? d32 : d48);
         }
     }
-    // point 4l+4 belongs to the next lane
-    d[4] = __shfl_down(d[0], 1, WAVE);
-    pdf[4] = __shfl_down(pdf[0], 1, WAVE);
     // inclusive sums of this lane's trapezoids: s[k] = seg(i0) + ... + seg(i0 + k)
     double s[4];
     double run = 0.0;
@@ -603,16 +623,20 @@ __global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *d
         if (i < nseg) run += (d[k + 1] - d[k]) * (pdf[k + 1] + pdf[k]) / 2.0;
         s[k] = run;
     }
-    double incl = run;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const double u = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += u;
-    }
-    // cdf[i0]: the sum of the lanes below; cdf[i0 + k + 1] = before + s[k]
-    const double below = __shfl_up(incl, 1, WAVE);
-    const double before = lane == 0 ? 0.0 : below;
-    const double total = __shfl(incl, WAVE - 1, WAVE);
+    // running sum of the lane totals: inside rows of sixteen lanes by DPP shifts (zeros come in
+    // at a row's start), then the totals of the rows before a lane's own.
+    // cdf[i0] = before: the sum of the lanes below; cdf[i0 + k + 1] = before + s[k]
+    double inrow = run;
+    inrow += dpp_f64<0x111>(inrow);                            // row_shr:1, 2, 4, 8
+    inrow += dpp_f64<0x112>(inrow);
+    inrow += dpp_f64<0x114>(inrow);
+    inrow += dpp_f64<0x118>(inrow);
+    const double r0 = lane_f64(inrow, 15), r1 = lane_f64(inrow, 31), r2 = lane_f64(inrow, 47),
+                 r3 = lane_f64(inrow, 63);
+    const int row = lane >> 4;
+    const double rows_before = row == 0 ? 0.0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2));
+    const double before = dpp_f64<0x111>(inrow) + rows_before;
+    const double total = ((r0 + r1) + r2) + r3;
     const double inv = 1. / total;
     const double conf[2] = {c_lo, c_hi};
     double res[2];
@@ -622,7 +646,7 @@ __global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *d
         const int src = ibest < npt ? ibest / 4 : 0;
         const int kk = ibest & 3;
         const double mine = kk == 0 ? d[0] : (kk == 1 ? d[1] : (kk == 2 ? d[2] : d[3]));
-        const double v = __shfl(mine, src, WAVE);
+        const double v = lane_f64(mine, src);                 // src is the same in every lane
         if (ibest < npt) ag = v;
     }
 #pragma unroll
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *d
                 const double slope = (chi - clo) / (dhi - dlo);
                 mine = dlo + (conf[q] - clo) / slope;
             }
-            r = __shfl(mine, src, WAVE);
+            r = lane_f64(mine, src);
         }
         res[q] = r;
     }
@@ -942,12 +966,30 @@ extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int
     size_t smem = (size_t)4 * 3 * npt * sizeof(double);
     dim3 grid((unsigned)ceil_div(ncell, 4));
     if (npt <= 256)
-        hipLaunchKernelGGL(profile_quantiles4_kernel, grid, dim3(256), 0, st, dom, cod, ncell, npt,
+        hipLaunchKernelGGL(profile_quantiles4_kernel<false>, grid, dim3(256), 0, st, dom, cod, ncell, npt,
                            conf_lo, conf_hi, aguess, xlo, xhi);
     else
         hipLaunchKernelGGL(profile_quantiles_kernel, grid, dim3(256), smem, st, dom, cod, ncell, npt,
                            conf_lo, conf_hi, aguess, xlo, xhi);
     GODOT_LAUNCH_CHECK("godot_profile_quantiles");
+    return GODOT_OK;
+}
+
+extern "C" int godot_profile_quantiles_linspace(const double *dom, const double *cod, int64_t ncell, int npt,
+                                                double conf_lo, double conf_hi, double *aguess, double *xlo,
+                                                double *xhi, godot_stream_t stream)
+{
+    if (npt > 256)      // long rows: the general kernel (its rows are staged in LDS either way)
+        return godot_profile_quantiles(dom, cod, ncell, npt, conf_lo, conf_hi, aguess, xlo, xhi, stream);
+    GODOT_ENTRY();
+    GODOT_REQUIRE(ncell >= 0, GODOT_E_INVALID, "godot_profile_quantiles_linspace: negative ncell");
+    GODOT_REQUIRE(npt >= 2, GODOT_E_UNSUPPORTED, "godot_profile_quantiles_linspace: npt must be at least 2");
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(dom && cod && aguess && xlo && xhi, GODOT_E_INVALID,
+                  "godot_profile_quantiles_linspace: null argument");
+    hipLaunchKernelGGL(profile_quantiles4_kernel<true>, dim3((unsigned)ceil_div(ncell, 4)), dim3(256), 0,
+                       (hipStream_t)stream, dom, cod, ncell, npt, conf_lo, conf_hi, aguess, xlo, xhi);
+    GODOT_LAUNCH_CHECK("godot_profile_quantiles_linspace");
     return GODOT_OK;
 }
 

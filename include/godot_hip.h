@@ -136,6 +136,18 @@ int godot_profile_quantiles(const double *dom, const double *cod,
                             double *aguess, double *xlo, double *xhi,
                             godot_stream_t stream);
 
+/* godot_profile_quantiles for rows whose abscissae are numpy.linspace(dom[c][0],
+ * dom[c][npt-1], npt) to the bit -- what godot_cell_logpdf and
+ * godot_cell_logpdf_profile write (get_logpdf, core.py:851-932, takes its grid
+ * from numpy.linspace): only the two ends of a row of dom are read and the
+ * abscissae are formed as those kernels form them, so the call moves half the
+ * bytes (the light curve of 4 10^5 cells: 0.71 GB instead of 1.42 GB).  Same
+ * results as godot_profile_quantiles on such rows, bit for bit; on other rows
+ * they are the quantiles of the linspace row, not of dom.                     */
+int godot_profile_quantiles_linspace(const double *dom, const double *cod, int64_t ncell, int npt,
+                                     double conf_lo, double conf_hi, double *aguess,
+                                     double *xlo, double *xhi, godot_stream_t stream);
+
 /* Assemble light-curve rows 1..5 of get_raw_lightcurve (core.py:1329-1334):
  * out[c] = {terr_days, alpha|UL, err_lo|0, err_hi|-1, TS}; column 0 (MJD of the
  * cell mid-time) is formed on the host in extended precision as the reference

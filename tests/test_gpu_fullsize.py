@@ -170,6 +170,59 @@ def test_c2_profile_grid_brackets_the_maximum(c2):
     # 5 steps; nearly all cells get there
     right = _n(cod[:, -1])
     assert np.median(np.abs(right + 30)) < 0.1 and (right < -20).mean() > 0.999
+    # spot rows against the oracle's get_logpdf: every 500th cell, abscissae and log-densities
+    pick = np.arange(0, n, 500)
+    dom_h, cod_h = _n(dom[pick]), _n(cod[pick])
+    we, lo, hi, S, B = _n(cr.we), _n(cr.lo), _n(cr.hi), _n(cr.S), _n(cr.B)
+    with np.errstate(all='ignore'):
+        for row, c in enumerate(pick):
+            cl = orc.CellLike(we[lo[c]:hi[c]], S[c], S[c] / B[c])
+            rd, rc = cl.get_logpdf(npt=200, dlogl=30)
+            assert np.abs(dom_h[row] - rd).max() <= RTOL * max(1.0, np.abs(rd).max()), c
+            assert np.abs(cod_h[row] - rc).max() <= RTOL * max(30.0, np.abs(rc).max()), c
+
+
+def test_c2_light_curve_reads_half_of_its_profile_rows(c2):
+    """get_flux_all / get_raw_lightcurve take the quantiles from the log-densities and the two
+    ends of every row of abscissae (godot_profile_quantiles_linspace): to the bit what
+    godot_profile_quantiles gives on the whole rows, for the rows of the fixed-background and of
+    the background-profile kernels (NaN rows of cells without a profile included); a row that is
+    not numpy.linspace of its ends is told apart by the general kernel only; and spot rows of
+    the light curve equal the oracle's raw_lightcurve."""
+    from godot_amd import core, ops
+    s, data, cells = c2
+    n = 150_000
+    sub = cells[:n]
+    cll = core.CellsLogLikelihood(sub)
+    assert cll._rows_linspace
+    dom, cod = cll._dom_d, cll._cod_d
+    same = lambda a, b: torch.equal(a.view(torch.int64), b.view(torch.int64))
+    for lv in ((0.05, 0.95), (0.159, 0.841), (0.5, 0.5)):
+        got = ops.profile_quantiles(dom, cod, lv[0], lv[1], linspace=True)
+        ref = ops.profile_quantiles(dom, cod, lv[0], lv[1])
+        assert all(same(g, r) for g, r in zip(got, ref)), lv
+    pd, pc, _ = ops.cell_logpdf_profile(cells[:2000].ranges(), dlogl=20, npt=100)
+    pd[7] = float('nan')
+    pc[7] = float('nan')
+    got = ops.profile_quantiles(pd, pc, 0.16, 0.84, linspace=True)
+    ref = ops.profile_quantiles(pd, pc, 0.16, 0.84)
+    assert all(same(g, r) for g, r in zip(got, ref))
+    bent = dom[:1000].clone()
+    bent[:, 100] = 0.5 * (bent[:, 100] + bent[:, 101])
+    assert not torch.equal(ops.profile_quantiles(bent, cod[:1000], 0.05, 0.95)[1],
+                           ops.profile_quantiles(bent, cod[:1000], 0.05, 0.95, linspace=True)[1])
+    lc = cll.get_raw_lightcurve()
+    pick = np.arange(0, n, 1500)
+    dom_h, cod_h = _n(dom[pick]), _n(cod[pick])
+    we, lo, hi, S, B = (_n(x) for x in (sub.we, sub.lo, sub.hi, sub.sexp, sub.bexp))
+    with np.errstate(all='ignore'):
+        clls = [orc.CellLike(we[lo[c]:hi[c]], S[c], S[c] / B[c]) for c in pick]
+        rdom, rcod = orc.cells_logpdf(clls, npt=200, dlogl=30)
+        ref = orc.raw_lightcurve(clls, _n(sub.starts)[pick], _n(sub.stops)[pick], rdom, rcod)
+    got = lc[pick]
+    assert np.array_equal(got[:, 4] == -1, ref[:, 4] == -1)
+    scale = np.maximum(1.0, np.abs(ref))
+    assert (np.abs(got - ref) <= 1e-7 * scale).all(), np.abs((got - ref) / scale).max()
 
 
 def test_c4_trig_sums_add_and_match_the_oracle_at_spot_frequencies():
