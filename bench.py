@@ -53,9 +53,9 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 peak
 NLIST = 4                  # photon lists a rank rotates through
 NSTREAM = max(1, int(os.environ.get('GODOT_BENCH_STREAMS', '3')))   # streams the timed fits are dealt over
 # hardware-counted FP64 work of the Z^2_2 kernel per (photon, frequency) evaluation:
-# profiles/r2_z2m_flops.json (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 passes on the timed kernel)
-Z2M_FLOP_FILE = os.path.join(REPO, 'profiles', 'r2_z2m_flops.json')
-FIT_TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r2_cell_fit_traffic.json')
+# profiles/r3_z2m_flops.json (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 passes on the timed kernel)
+Z2M_FLOP_FILE = os.path.join(REPO, 'profiles', 'r3_z2m_flops.json')
+FIT_TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r3_cell_fit_traffic.json')
 
 
 def parse():
@@ -365,6 +365,26 @@ def run_rank(args):
                  single_stream=dict(ms_per_step=single_s / nsingle * 1e3, fits_timed=nsingle,
                                     cells_per_s_this_rank=float(sum(ncells[i % NLIST] for i in range(nsingle)))
                                     / single_s))
+
+    # the four lists as ONE cell list fitted by one launch (390 MB touched per launch: more than
+    # the last-level cache): what a fit costs when the ramp and the tail of a 46-us launch are
+    # spread over four times the work
+    if not args.no_extra:
+        shift = np.concatenate([[0], np.cumsum([cr.nph for cr in crs])])
+        joined = ops.CellRanges(torch.cat([cr.we for cr in crs]),
+                                torch.cat([cr.lo + int(shift[j]) for j, cr in enumerate(crs)]),
+                                torch.cat([cr.hi + int(shift[j]) for j, cr in enumerate(crs)]),
+                                torch.cat([cr.S for cr in crs]), torch.cat([cr.B for cr in crs]),
+                                photons=int(sum(nphs)))
+        ops.cell_fit(joined)
+        j_ms = event_time_ms(lambda i: ops.cell_fit(joined), 50)
+        j_bytes = sum(8.0 * n + 8.0 * (c + 1) + 32.0 * c for n, c in zip(nphs, ncells))
+        extra['four_lists_one_launch'] = dict(ms=j_ms, ms_per_list=j_ms / NLIST, cells=int(joined.ncell),
+                                              algorithmic_GBps=j_bytes / (j_ms * 1e-3) / 1e9,
+                                              frac_of_hbm_peak=j_bytes / (j_ms * 1e-3) / 8e12,
+                                              cells_per_s=joined.ncell / (j_ms * 1e-3))
+        del joined
+        torch.cuda.empty_cache()
 
     # ---- strong scaling, collectives inside the timed region -----------------------
     if not args.no_extra:
