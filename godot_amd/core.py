@@ -1632,27 +1632,16 @@ def get_cells_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_expo
     return SourceBatch(cells, source, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64))
 
 
-def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
-                         compact_tables=None):
-    """Data.get_cells(tstart, tstop, tcell, time_series_only=True, use_barycenter=False) for
-    every Data object of `sources` (reference core.py:1958-2206 with the return of 2185-2192):
-    a list of CellTimeSeries, one per source, the same bits as the per-source calls.  The
-    edges, exposures, dead times and photon ranges of all sources come from the two launches
-    of ops.bin_sources, the weight moments of all cells from one more, the trimming from one
-    selection: the input of a power spectrum per source (power_spectrum_fft) without a
-    dozen small launches per source.  compact_tables as for get_cells_batch."""
-    if tcell is None:
-        raise ValueError('get_timeseries_batch needs a cell length')
-    if not sources:
-        raise ValueError('no sources')
+def _timeseries_columns(sources, tstart, tstop, tcell, trim_zero_exposure, quiet, compact_tables):
+    """The nine columns of CellTimeSeries for all sources side by side, the offsets of the sources
+    in them and the spans binned; None where the batched binning does not apply."""
     spans = None
     if not any(d.sexposure is not None for d in sources):
         spans = [d._uniform_cells(tstart, tstop, tcell, quiet) for d in sources]
         if any(not tc > 0 or nc < 1 for _, _, tc, nc in spans):
             spans = None         # a span that ends before it begins: whatever get_cells makes of it
     if spans is None:
-        return [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
-                            time_series_only=True, use_barycenter=False, quiet=quiet) for d in sources]
+        return None
     desc = _batch_descriptors(sources, spans, compact_tables)
     starts, stops, exp, sexp, bexp, dead, lo, hi, source = ops.bin_sources(desc, deadtime_too=True)
     we = _joined([d.we for d in sources])
@@ -1669,7 +1658,34 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
         mask = ~(cols[2] > 0)
         for c in cols[2:8]:
             c[mask] = 0
-    off = np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64)
+    return cols, np.concatenate([[0], np.cumsum(ncl)]).astype(np.int64), spans
+
+
+def _span_sampling(span):
+    """tsamp and tspan of an untrimmed series on the edges i * tcell + t0, rounded as the kernels
+    (and numpy) round them: what CellTimeSeries.tsamp() / tspan() read off the device."""
+    t0, _, tc, nc = span
+    return (1.0 * tc + t0) - (0.0 * tc + t0), (float(nc) * tc + t0) - (0.0 * tc + t0)
+
+
+def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero_exposure=True, quiet=True,
+                         compact_tables=None):
+    """Data.get_cells(tstart, tstop, tcell, time_series_only=True, use_barycenter=False) for
+    every Data object of `sources` (reference core.py:1958-2206 with the return of 2185-2192):
+    a list of CellTimeSeries, one per source, the same bits as the per-source calls.  The
+    edges, exposures, dead times and photon ranges of all sources come from the two launches
+    of ops.bin_sources, the weight moments of all cells from one more, the trimming from one
+    selection: the input of a power spectrum per source (power_spectrum_fft) without a
+    dozen small launches per source.  compact_tables as for get_cells_batch."""
+    if tcell is None:
+        raise ValueError('get_timeseries_batch needs a cell length')
+    if not sources:
+        raise ValueError('no sources')
+    made = _timeseries_columns(sources, tstart, tstop, tcell, trim_zero_exposure, quiet, compact_tables)
+    if made is None:
+        return [d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell, trim_zero_exposure=trim_zero_exposure,
+                            time_series_only=True, use_barycenter=False, quiet=quiet) for d in sources]
+    cols, off, spans = made
     out = []
     for k in range(len(sources)):
         ts = object.__new__(CellTimeSeries)
@@ -1679,11 +1695,9 @@ def get_timeseries_batch(sources, tstart=None, tstop=None, tcell=None, trim_zero
         ts.timesys = 'topocentric'
         ts.minimum_exposure = 0
         if not trim_zero_exposure:
-            # untrimmed: the first and last edges are those of the span, edge i = i * tcell + t0
-            # rounded as the kernels (and numpy) round it; no device read for tsamp() / tspan()
-            t0, _, tc, nc = spans[k]
-            ts._tsamp = (1.0 * tc + t0) - (0.0 * tc + t0)
-            ts._tspan = (float(nc) * tc + t0) - (0.0 * tc + t0)
+            # untrimmed: the first and last edges are those of the span; no device read for
+            # tsamp() / tspan()
+            ts._tsamp, ts._tspan = _span_sampling(spans[k])
         out.append(ts)
     return out
 
@@ -1702,7 +1716,7 @@ class SourceResults(object):
 
 
 def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32, dfgoal=None,
-                keep_spectra=False, compact_tables=None, timings=None):
+                keep_spectra=False, compact_tables=None, timings=None, nstream=3):
     """Many sources as one job: for every Data object the cells of length tcell_fit fitted
     (Data.get_cells + the per-cell maximisation of CellsLogLikelihood, reference
     core.py:1958, 1070) and the power spectra of its time series of tcell_ps bins
@@ -1710,8 +1724,11 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
     tables of all sources are built by a handful of launches, the cells of all sources are
     binned by two and fitted by one; the time series are binned `chunk` sources at a time
     (a source's series at 300-s bins is 10^6 bins of nine columns) and transformed one source
-    after another.  The host reads results back once, at the end.  `timings`: a dict that
-    receives the seconds spent per stage (the device is then waited for after every stage)."""
+    after another, dealt over `nstream` HIP streams: a spectrum is half a dozen launches of
+    40-110 us, each of which ramps up and drains on its own, and the launches of the next
+    source's spectrum fill what one leaves idle.  The host reads results back once, at the end.
+    `timings`: a dict that receives the seconds spent per stage (the device is then waited for
+    after every stage)."""
     if not sources:
         raise ValueError('no sources')
     dev = sources[0].device
@@ -1732,21 +1749,83 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
     lap('fit')
     peaks, df, spectra = [], [], ([] if keep_spectra else None)
     chunk = max(1, int(chunk))
+    here = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(dev) for _ in range(max(1, int(nstream)))] if int(nstream) > 1 else [here]
+    work = [None] * len(side)                    # a transform workspace per stream, kept over the job
+
+    def fork():
+        for st in side:
+            if st is not here:
+                st.wait_stream(here)
+
+    def join():
+        for st in side:
+            if st is not here:
+                here.wait_stream(st)
+
     for at in range(0, len(sources), chunk):
-        series = get_timeseries_batch(sources[at:at + chunk], tstart=tstart, tstop=tstop, tcell=tcell_ps,
-                                      trim_zero_exposure=False, compact_tables=compact_tables)
+        part = sources[at:at + chunk]
+        made = _timeseries_columns(part, tstart, tstop, tcell_ps, False, True, compact_tables)
+        if made is None:
+            # sources the batched binning does not take: one call after the other
+            for d in part:
+                ser = d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell_ps, trim_zero_exposure=False,
+                                  time_series_only=True, use_barycenter=False, quiet=True)
+                l, tsamp, p0, p1, pb, _ = _power_spectrum_parts(ser, dfgoal=dfgoal)
+                v = [torch.max(p[1:], 0) for p in (p0, p1, pb)]
+                peaks.append(torch.stack([torch.stack([m.values for m in v]),
+                                          torch.stack([m.indices for m in v]).to(F64)]).unsqueeze(0))
+                df.append((1.0 / l, tsamp))
+                if keep_spectra:
+                    spectra.append((l, tsamp, p0, p1, pb))
+            lap('spectra')
+            continue
+        cols, off, spans = made
+        sexp, bexp, counts, W, WW = cols[3], cols[4], cols[5], cols[6], cols[7]
+        # the series power_spectrum_fft derives (core.py:2654-2661), for all sources of the chunk at once
+        cf = counts.to(F64)
+        Wb = cf - W
+        WbWb = cf - 2 * W + WW
         lap('time_series')
-        for ser in series:
-            l, tsamp, p0, p1, pb, _ = _power_spectrum_parts(ser, dfgoal=dfgoal)
-            v = [torch.max(p[1:], 0) for p in (p0, p1, pb)]
-            peaks.append(torch.stack([torch.stack([m.values for m in v]),
-                                      torch.stack([m.indices for m in v]).to(F64)]))
-            df.append((1.0 / l, tsamp))
+        # padded length of every source's transform, as power_spectrum_fft chooses it (core.py:2667-2671)
+        ls, samp = [], []
+        for sp in spans:
+            tsamp, tspan = _span_sampling(sp)
+            goal = 0.2 / tspan if dfgoal is None else dfgoal
+            ls.append(2 ** (int(np.log2(1. / (tsamp * goal))) + 1))
+            samp.append(tsamp)
+        for k, l in enumerate(ls):
+            if l < int(off[k + 1] - off[k]):
+                raise NotImplementedError('dfgoal gives a transform shorter than the series')
+        same = all(l == ls[0] for l in ls)
+        buf = torch.empty((len(part), 3, ls[0] // 4 + 1), dtype=F64, device=dev) if same else None
+        fork()
+        for k in range(len(part)):
+            j = k % len(side)
+            st = side[j]
+            c0, c1 = int(off[k]), int(off[k + 1])
+            with torch.cuda.stream(st):
+                if work[j] is None or work[j].numel() < ops._lib.lib.godot_power_spectrum_workspace_bytes(ls[k]):
+                    work[j] = ops.power_spectrum_workspace(ls[k], dev)
+                out = (buf[k, 0], buf[k, 1], buf[k, 2]) if same else None
+                p0, p1, pb, _ = ops.power_spectrum_fft(W[c0:c1], WW[c0:c1], sexp[c0:c1], Wb[c0:c1], WbWb[c0:c1],
+                                                       bexp[c0:c1], ls[k], out=out, workspace=work[j])
+                if not same:
+                    v = [torch.max(p[1:], 0) for p in (p0, p1, pb)]
+                    peaks.append(torch.stack([torch.stack([m.values for m in v]),
+                                              torch.stack([m.indices for m in v]).to(F64)]).unsqueeze(0))
+            df.append((1.0 / ls[k], samp[k]))
             if keep_spectra:
-                spectra.append((l, tsamp, p0, p1, pb))
-        del series
+                spectra.append((ls[k], samp[k], p0, p1, pb))
+        join()
+        if same:
+            m = torch.max(buf[:, :, 1:], 2)                          # one reduction for the chunk
+            peaks.append(torch.stack([m.values, m.indices.to(F64)], 1))
+        # (what the side streams read and wrote belongs to this stream's allocator; join() made
+        # this stream wait for them, so it may be handed out again from here on)
+        del cols, cf, Wb, WbWb, buf
         lap('spectra')
-    pk = torch.stack(peaks).cpu().numpy()           # the one read of the job
+    pk = torch.cat(peaks).cpu().numpy()           # the one read of the job
     lap('read_back')
     df = np.array(df)
     # bin i stands at (i * (1 / l)) / tsamp, as power_spectrum_fft forms its frequencies

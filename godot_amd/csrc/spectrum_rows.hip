@@ -76,7 +76,7 @@ __device__ __forceinline__ void twiddle_powers(cplx (&v)[N], cplx w)
 template <int T>
 struct Team {
     static constexpr int T3 = T / 16;
-    static constexpr int RS = ((T3 * 17 + 3) / 4) * 4;   // row stride of the exchanges
+    static constexpr int RS = T3 == 1 ? 18 : ((T3 * 17 + 3) / 4) * 4;   // row stride of the exchanges
     static constexpr int REGION = 16 * RS;               // elements, >= 16 T
 };
 
@@ -700,11 +700,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 namespace godot_spectrum {
 
-// The path takes transforms whose rows have 1 024 or 2 048 points (l = 2^24, 2^25) and series
-// that need no wrapping (n <= l/2).
+// The path takes transforms whose rows have 512, 1 024 or 2 048 points (l = 2^23, 2^24, 2^25) and
+// series that need no wrapping (n <= l/2).
 bool rows_path_applies(int64_t n, int64_t l)
 {
-    return (l == ((int64_t)1 << 24) || l == ((int64_t)1 << 25)) && n >= 1 && n <= l / 2;
+    return (l == ((int64_t)1 << 23) || l == ((int64_t)1 << 24) || l == ((int64_t)1 << 25)) && n >= 1 && n <= l / 2;
 }
 
 size_t rows_path_workspace_bytes(int64_t l)
@@ -757,9 +757,12 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
     if (B == 2048) {
         ra.ngroup = HALF / 4 + 1;
         hipLaunchKernelGGL(rows2048_kernel, dim3((unsigned)(8 + ceil_div(ra.ngroup - 1, 8) * 8)), dim3(512), 0, st, ra);
-    } else {
+    } else if (B == 1024) {
         ra.ngroup = HALF / 8 + 1;
         hipLaunchKernelGGL(rows_kernel<64>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
+    } else {
+        ra.ngroup = HALF / 16 + 1;
+        hipLaunchKernelGGL(rows_kernel<32>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
     }
 }
 

@@ -594,18 +594,37 @@ def rfft(x, l):
     return out
 
 
-def power_spectrum_fft(W, WW, S, Wb, WbWb, B, l, want_amps=False):
+def power_spectrum_workspace(l, dev):
+    """A workspace for power_spectrum_fft calls of padded length up to l: a caller that makes
+    many calls on one stream may allocate it once and hand it to every call."""
+    return _workspace(_lib.lib.godot_power_spectrum_workspace_bytes(l), dev)
+
+
+def power_spectrum_fft(W, WW, S, Wb, WbWb, B, l, want_amps=False, out=None, workspace=None):
+    """out: three contiguous float64 tensors of l // 4 + 1 entries to take P_0, P_1, P_b (rows
+    of a larger array, say); workspace: power_spectrum_workspace(l or more) on the same device,
+    not in use by a call on another stream."""
     for t, nm in ((W, 'W'), (WW, 'WW'), (S, 'S'), (Wb, 'Wb'), (WbWb, 'WbWb'), (B, 'B')):
         _dev_check(t, F64, nm)
         if t.numel() != W.numel():
             raise ValueError('the six series must have equal lengths')
     n, dev = W.numel(), W.device
     nk = l // 4 + 1
-    p0 = torch.empty(nk, dtype=F64, device=dev)
-    p1 = torch.empty(nk, dtype=F64, device=dev)
-    pb = torch.empty(nk, dtype=F64, device=dev)
+    if out is None:
+        p0 = torch.empty(nk, dtype=F64, device=dev)
+        p1 = torch.empty(nk, dtype=F64, device=dev)
+        pb = torch.empty(nk, dtype=F64, device=dev)
+    else:
+        p0, p1, pb = out
+        for t, nm in ((p0, 'out[0]'), (p1, 'out[1]'), (pb, 'out[2]')):
+            _dev_check(t, F64, nm)
+            if t.numel() != nk or t.device != dev:
+                raise ValueError('%s must hold l // 4 + 1 entries on the device of the series' % nm)
     amps = torch.empty((8, nk), dtype=F64, device=dev) if want_amps else None
-    ws = _workspace(_lib.lib.godot_power_spectrum_workspace_bytes(l), dev)
+    need = _lib.lib.godot_power_spectrum_workspace_bytes(l)
+    ws = workspace if workspace is not None else _workspace(need, dev)
+    if ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < need:
+        raise ValueError('the workspace is too small for l = %d, or not on the device of the series' % l)
     with torch.cuda.device(dev):
         _lib.call('godot_power_spectrum_fft', _p(W), _p(WW), _p(S), _p(Wb), _p(WbWb), _p(B), n, l,
                   _p(p0), _p(p1), _p(pb), _p(amps), _p(ws), ws.numel(), _stream(dev))

@@ -299,10 +299,11 @@ def test_spectrum_whose_last_pass_forms_the_estimators(lg, frac):
     assert (np.abs(got[:, 1:] - ramps[:, 1:]) <= 1e-8 * sc).all()
 
 
-@pytest.mark.parametrize('lg,nbin', [(24, 1_893_456), (24, 700), (24, 1 << 23), (24, 1_048_577),
+@pytest.mark.parametrize('lg,nbin', [(23, 1_051_920), (23, 1 << 22), (23, 900), (23, 524_289),
+                                     (24, 1_893_456), (24, 700), (24, 1 << 23), (24, 1_048_577),
                                      (25, 3_786_912), (25, 1 << 24), (25, 5000)])
 def test_long_series_transformed_by_columns_and_rows(lg, nbin):
-    """Padded lengths 2^24 and 2^25 take the path of two trips through memory (columns of the
+    """Padded lengths 2^23, 2^24 and 2^25 take the path of two trips through memory (columns of the
     padded series, then rows with the estimators): every bin and the amplitudes against numpy's
     transforms, and against the three-trip path of the same library, for series that fill a
     tenth of the padded length (the default padding), half of it (the most the path takes: every
