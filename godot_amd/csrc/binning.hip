@@ -834,20 +834,31 @@ struct UniformEdge {
 // cumulative exposures at the query times: core.py:1806-1832.  Called by every thread of a
 // 256-thread workgroup (it synchronises); the workgroup serves queries 256 * blockIdx.x ...
 // The row a query falls in: false for the threads past the last query.
+// `bracket`: null, or the rows of this workgroup's first query and of the next workgroup's first
+// (the last query's for the last workgroup), found by a launch ahead: sources_brackets_kernel.
+// find_row = false leaves idx to the caller (who searches a copy of the bracket's rows in LDS).
 template <class TimeAt>
 __device__ __forceinline__ bool exposure_query_row(const ExposureLoad &ld, int64_t n_ft2, const TimeAt times,
                                                    int64_t n_t, int64_t &k, double &t, int64_t &idx, int64_t &row_first,
-                                                   int64_t &row_last)
+                                                   int64_t &row_last, const int64_t *bracket = nullptr,
+                                                   bool find_row = true, int64_t wg = -1)
 {
+    if (wg < 0) wg = blockIdx.x;   // which 256 (blockDim.x) queries the workgroup serves
     // sorted queries (cell edges): the rows of the workgroup's first and last query bracket
     // the rows of all the others; those two are searched for by a wavefront each
     __shared__ double s_t[2];
     __shared__ int64_t s_i[2];
-    k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t kb = (int64_t)blockIdx.x * blockDim.x;
+    k = wg * blockDim.x + threadIdx.x;
+    const int64_t kb = wg * blockDim.x;
     const int64_t kl = (kb + blockDim.x < n_t ? kb + blockDim.x : n_t) - 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave == 0) {
+    if (bracket) {
+        if (threadIdx.x < 2) {
+            const int64_t e = threadIdx.x == 0 ? kb : (kb + blockDim.x < n_t ? kb + blockDim.x : n_t - 1);
+            s_t[threadIdx.x] = times(e);
+            s_i[threadIdx.x] = bracket[threadIdx.x];
+        }
+    } else if (wave == 0) {
         const double tb = times(kb);
         const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tb);
         if (lane == 0) {
@@ -855,7 +866,7 @@ __device__ __forceinline__ bool exposure_query_row(const ExposureLoad &ld, int64
             s_i[0] = r;
         }
     }
-    if (wave == (int)((kl - kb) >> 6)) {
+    if (!bracket && wave == (int)((kl - kb) >> 6)) {
         const double tl = times(kl);
         const int64_t r = bound_by_wave<false>(ld.tstop, n_ft2, tl);
         if (lane == 0) {
@@ -868,6 +879,7 @@ __device__ __forceinline__ bool exposure_query_row(const ExposureLoad &ld, int64
     row_last = s_i[1];
     if (k >= n_t) return false;
     t = times(k);
+    if (!find_row) return true;
     if (s_t[0] <= t && t <= s_t[1]) {
         // The rows of a spacecraft file are evenly spaced but for the gaps: the row is guessed
         // by proportion inside the bracket and the guess and its two neighbours are looked at
@@ -904,11 +916,12 @@ __device__ __forceinline__ Quad exposure_within_row(double t, const ExpRow &r, c
 }
 template <class TimeAt>
 __device__ __forceinline__ void exposure_query_body(const ExposureLoad &ld, const Quad *cum, const ExpRow *rows,
-                                                    int64_t n_ft2, const TimeAt times, int64_t n_t, Quad *at)
+                                                    int64_t n_ft2, const TimeAt times, int64_t n_t, Quad *at,
+                                                    const int64_t *bracket = nullptr, int64_t wg = -1)
 {
     int64_t k, idx, i0, i1;
     double t;
-    if (!exposure_query_row(ld, n_ft2, times, n_t, k, t, idx, i0, i1)) return;
+    if (!exposure_query_row(ld, n_ft2, times, n_t, k, t, idx, i0, i1, bracket, true, wg)) return;
     at[k] = exposure_within_row(t, rows[idx], cum[idx]);
 }
 
@@ -925,30 +938,55 @@ __host__ __device__ inline int64_t ck_records(int64_t n) { return (n + CK_ROWS -
 // dead time of a row; the two multiples of the exposure are formed as ExposureLoad forms
 // them) and the queries add from there; a thread that walks its rows in memory waits for
 // every row in turn (measured 4.3 ms against 1.1 ms for 8.4 10^6 cells).
-constexpr int CK_LDS_ROWS = 3072;
+constexpr int CK_LDS_ROWS = 1536;
 template <class TimeAt>
 __device__ __forceinline__ void exposure_query_ck_body(const ExposureLoad &ld, const Quad *ck, int64_t n_ft2,
-                                                       const TimeAt times, int64_t n_t, Quad *at)
+                                                       const TimeAt times, int64_t n_t, Quad *at,
+                                                       const int64_t *bracket = nullptr, int64_t wg = -1)
 {
-    __shared__ double2 s_row[CK_LDS_ROWS];
-    int64_t k, idx, i0, i1;
+    // a spare slot after every sixteen rows: the queries of neighbouring lanes start their walks at
+    // the heads of neighbouring groups of sixteen, which would otherwise all lie on one LDS bank
+    // (measured: four cycles of bank conflict for every cycle of LDS work)
+    __shared__ double2 s_row[CK_LDS_ROWS + CK_LDS_ROWS / CK_ROWS];
+    __shared__ double s_stop[CK_LDS_ROWS];
+    auto slot = [](int64_t i) { return i + (i >> 4); };
+    int64_t k, idx = 0, i0, i1;
     double t;
-    const bool valid = exposure_query_row(ld, n_ft2, times, n_t, k, t, idx, i0, i1);
+    // with the bracket known ahead, the rows are fetched first and every query finds its row in
+    // the LDS copy of their TSTOP: no chain of dependent loads from memory per query
+    const bool valid = exposure_query_row(ld, n_ft2, times, n_t, k, t, idx, i0, i1, bracket, bracket == nullptr, wg);
     const int64_t r_lo = (i0 < n_ft2 ? i0 : n_ft2 - 1) / CK_ROWS * CK_ROWS;
     const int64_t r_hi = i1 < n_ft2 ? i1 : n_ft2 - 1;
     const bool staged = !ld.sexposure && r_hi >= r_lo && r_hi - r_lo < CK_LDS_ROWS;   // the same for all threads
     if (staged) {
-        for (int64_t r = r_lo + threadIdx.x; r <= r_hi; r += blockDim.x)
-            s_row[r - r_lo] = double2{ld.exposure[r], __dsub_rn(__dsub_rn(ld.tstop[r], ld.tstart[r]), ld.livetime[r])};
+        for (int64_t r = r_lo + threadIdx.x; r <= r_hi; r += blockDim.x) {
+            const double stop = ld.tstop[r];
+            s_row[slot(r - r_lo)] = double2{ld.exposure[r], __dsub_rn(__dsub_rn(stop, ld.tstart[r]), ld.livetime[r])};
+            s_stop[r - r_lo] = stop;
+        }
         __syncthreads();
     }
     if (!valid) return;
+    if (bracket) {
+        // lower_bound(TSTOP, t) lies between the rows of the bracket's ends
+        int64_t lo = i0 < n_ft2 ? i0 : n_ft2 - 1, hi = r_hi;
+        if (staged) {
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (s_stop[mid - r_lo] < t) lo = mid + 1;
+                else hi = mid;
+            }
+            idx = lo;
+        } else {
+            idx = lower_bound_in(ld.tstop, lo, hi, t);
+        }
+    }
     const int64_t j = idx / CK_ROWS;
     int64_t r = j * CK_ROWS;
     Quad x, c;
     if (staged && r >= r_lo && idx <= r_hi) {
         auto row = [&](int64_t i) {
-            const double2 v = s_row[i - r_lo];
+            const double2 v = s_row[slot(i - r_lo)];
             return Quad{v.x, __dmul_rn(ld.s_over_e, v.x), __dmul_rn(ld.b_over_e, v.x), v.y};
         };
         x = row(r);
@@ -1151,20 +1189,63 @@ inline size_t table_rows_bytes(int64_t n) { return align256(sizeof(ExpRow) * (si
 // from `first`; its descriptor says where its tables and photons are and where its cells go.
 // Pass one: the running sums at the ncell + 1 edges of every source (source k's stand at
 // at[cell_offset + k ...], one more entry than it has cells).
-__global__ __launch_bounds__(256) void sources_query_kernel(const godot_source_cells *src, int64_t first, Quad *at)
+// Workgroups go to the eight XCDs (each with an L2 of its own) in turn: the workgroups that one XCD
+// receives one after the other take the same piece (chunk, stretch of edges) for table after
+// table, so that what the tables share is fetched into that L2 once.  Grids are multiples of 8 n.
+__device__ __forceinline__ void xcd_deal(int64_t w, int64_t n, int64_t &which, int64_t &piece)
+{
+    const int64_t xcd = w & 7, q = w >> 3;
+    which = q % n;
+    piece = (q / n) * 8 + xcd;
+}
+// Where the brackets of source k's workgroups stand: one entry per workgroup of 256 edges and one
+// more; the regions of consecutive sources do not overlap (their edges stand at cell_offset + k,
+// ascending, at least ncell + 1 apart).
+constexpr int SQ_THREADS = 128;   // edges per workgroup of sources_query_kernel
+__host__ __device__ inline int64_t bracket_offset(int64_t cell_offset, int64_t k)
+{
+    return (cell_offset + k) / SQ_THREADS + 2 * k;
+}
+__host__ __device__ inline size_t bracket_entries(int64_t nsrc, int64_t total_cells)
+{
+    return (size_t)((total_cells + nsrc) / SQ_THREADS + 2 * nsrc + 2);
+}
+// The table row of the first edge of every workgroup of sources_query_kernel (and of the last
+// edge of all): a search over the whole table each, all of them at once, so that the workgroups
+// themselves start from a bracket instead of two searches of their own.
+__global__ __launch_bounds__(256) void sources_brackets_kernel(const godot_source_cells *src, int64_t first,
+                                                               int64_t *brackets)
 {
     const int64_t k = first + blockIdx.y;
     const godot_source_cells s = src[k];
     const int64_t n_t = s.ncell + 1;
-    if (s.ncell <= 0 || (int64_t)blockIdx.x * blockDim.x >= n_t) return;   // the whole workgroup
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s.ncell <= 0 || g > (n_t + SQ_THREADS - 1) / SQ_THREADS) return;
+    const int64_t e = SQ_THREADS * g < n_t ? SQ_THREADS * g : n_t - 1;
+    const UniformEdge edge{s.t0, s.tcell, 0};
+    brackets[bracket_offset(s.cell_offset, k) + g] = lower_bound(s.tstop, s.n_ft2, edge(e));
+}
+// Consecutive workgroups serve the same stretch of edges for different sources (xcd_deal): sources
+// over one spacecraft file read the same pieces of TSTART, TSTOP and LIVETIME then (from the cache;
+// dealt source after source, every source streams all three again).
+__global__ __launch_bounds__(SQ_THREADS) void sources_query_kernel(const godot_source_cells *src, int64_t first,
+                                                                   int64_t nsrc, Quad *at, const int64_t *brackets)
+{
+    int64_t which, wg;
+    xcd_deal(blockIdx.x, nsrc, which, wg);
+    const int64_t k = first + which;
+    const godot_source_cells s = src[k];
+    const int64_t n_t = s.ncell + 1;
+    if (s.ncell <= 0 || wg * blockDim.x >= n_t) return;   // the whole workgroup
     ExposureLoad ld{s.tstart, s.tstop, s.exposure, s.livetime, s.s_over_e, s.b_over_e, s.sexposure, s.bexposure};
+    const int64_t *br = brackets + bracket_offset(s.cell_offset, k) + wg;
     if (s.checkpoints)   // uniform over the workgroup
         exposure_query_ck_body(ld, (const Quad *)s.table, s.n_ft2, UniformEdge{s.t0, s.tcell, 0}, n_t,
-                               at + s.cell_offset + k);
+                               at + s.cell_offset + k, br, wg);
     else
         exposure_query_body(ld, (const Quad *)s.table,
                             (const ExpRow *)((const char *)s.table + table_sums_bytes(s.n_ft2)), s.n_ft2,
-                            UniformEdge{s.t0, s.tcell, 0}, n_t, at + s.cell_offset + k);
+                            UniformEdge{s.t0, s.tcell, 0}, n_t, at + s.cell_offset + k, br, wg);
 }
 
 // Checkpointed running sums of many tables at once (see godot_exposure_checkpoints in the
@@ -1178,18 +1259,18 @@ struct CkSource {
     int32_t *by_walk;
     Quad *ck;
 };
-// Workgroup w of these launches works on chunk w / ntab of table w % ntab: the tables of one
-// spacecraft file share TSTART, TSTOP and LIVETIME, and workgroups that run side by side then
-// read the same piece of them (from the cache, once the first has fetched it).
+// Consecutive workgroups of these launches work on the same chunk of different tables (xcd_deal):
+// the tables of one spacecraft file share TSTART, TSTOP and LIVETIME, and workgroups that run side
+// by side then read the same piece of them (from the cache, once the first has fetched it).
 // Built for throughput where the single-table kernels above are built for latency: a thread
 // takes eight consecutive rows straight from memory (no staging of the chunk in LDS, which
 // held those kernels to one workgroup a CU) and the threads' adders are composed by wavefront
 // shuffles.
 __device__ __forceinline__ bool ck_which(const CkSource *src, int64_t ntab, const CkSource *&s, int64_t &chunk)
 {
-    const int64_t w = blockIdx.x;
-    s = src + w % ntab;
-    chunk = w / ntab;
+    int64_t t;
+    xcd_deal(blockIdx.x, ntab, t, chunk);
+    s = src + t;
     return chunk < s->nchunk;
 }
 __global__ __launch_bounds__(CS_THREADS) void ck_totals_kernel(const CkSource *src, int64_t ntab)
@@ -1742,7 +1823,8 @@ extern "C" int godot_bin_photons(const double *ti, int64_t nph, double start0, c
 extern "C" size_t godot_bin_sources_workspace_bytes(int64_t nsrc, int64_t total_cells)
 {
     if (nsrc < 0 || total_cells < 0) return 0;
-    return align256(sizeof(godot_source_cells) * (size_t)nsrc) + align256(sizeof(Quad) * (size_t)(total_cells + nsrc));
+    return align256(sizeof(godot_source_cells) * (size_t)nsrc) + align256(sizeof(Quad) * (size_t)(total_cells + nsrc)) +
+           align256(sizeof(int64_t) * bracket_entries(nsrc, total_cells));
 }
 
 extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc, int64_t total_cells,
@@ -1780,6 +1862,7 @@ extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc
     hipStream_t st = (hipStream_t)stream;
     godot_source_cells *d_src = (godot_source_cells *)workspace;
     Quad *at = (Quad *)((char *)workspace + align256(sizeof(godot_source_cells) * (size_t)nsrc));
+    int64_t *brackets = (int64_t *)((char *)at + align256(sizeof(Quad) * (size_t)(total_cells + nsrc)));
     // pageable host memory: the call returns once the table has been staged, the caller may reuse
     // it.  The runtime stages such a copy only after what was queued on the stream before it has
     // finished, so this call waits for the stream's earlier work (a caller that wants the two
@@ -1790,8 +1873,14 @@ extern "C" int godot_bin_sources(const godot_source_cells *sources, int64_t nsrc
     constexpr int64_t MAX_Y = 65535;
     for (int64_t first = 0; first < nsrc; first += MAX_Y) {
         const unsigned ny = (unsigned)(nsrc - first < MAX_Y ? nsrc - first : MAX_Y);
-        hipLaunchKernelGGL(sources_query_kernel, dim3((unsigned)ceil_div(max_ncell + 1, 256), ny), dim3(256), 0, st,
-                           (const godot_source_cells *)d_src, first, at);
+        const int64_t nwg = ceil_div(max_ncell + 1, SQ_THREADS);
+        hipLaunchKernelGGL(sources_brackets_kernel, dim3((unsigned)ceil_div(nwg + 1, 256), ny), dim3(256), 0, st,
+                           (const godot_source_cells *)d_src, first, brackets);
+        GODOT_REQUIRE((nwg + 8) * (int64_t)ny < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED,
+                      "godot_bin_sources: %lld sources of up to %lld cells in one call", (long long)ny,
+                      (long long)max_ncell);
+        hipLaunchKernelGGL(sources_query_kernel, dim3((unsigned)(ceil_div(nwg, 8) * 8 * ny)), dim3(SQ_THREADS), 0, st,
+                           (const godot_source_cells *)d_src, first, (int64_t)ny, at, (const int64_t *)brackets);
         hipLaunchKernelGGL(sources_cells_kernel, dim3((unsigned)ceil_div(max_ncell, 256), ny), dim3(256), 0, st,
                            (const godot_source_cells *)d_src, first, (const Quad *)at, starts, stops, out_exp,
                            out_sexp, out_bexp, out_dead, lo, hi, source);
@@ -1877,10 +1966,10 @@ extern "C" int godot_exposure_checkpoints(const godot_exposure_rows *tables, int
         const CkSource *d = d_src + first;
         if (any_short) hipLaunchKernelGGL(ck_serial_kernel, dim3(1, ny), dim3(64), 0, st, d);
         if (max_chunks == 0) continue;
-        GODOT_REQUIRE(max_chunks * nt < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED,
+        GODOT_REQUIRE((max_chunks + 8) * nt < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED,
                       "godot_exposure_checkpoints: %lld tables of up to %lld rows in one call", (long long)nt,
                       (long long)(max_chunks * CS_CHUNK));
-        const unsigned nw = (unsigned)(max_chunks * nt);
+        const unsigned nw = (unsigned)(ceil_div(max_chunks, 8) * 8 * nt);
         hipLaunchKernelGGL(ck_totals_kernel, dim3(nw), dim3(CS_THREADS), 0, st, d, nt);
         hipLaunchKernelGGL(ck_estimate_kernel, dim3(ny), dim3(1024), 0, st, d);
         hipLaunchKernelGGL(ck_adders_kernel, dim3(nw), dim3(CS_THREADS), 0, st, d, nt);
