@@ -461,11 +461,11 @@ __device__ __forceinline__ void row_load(cplx (&v)[16], const cplx *__restrict__
     __builtin_amdgcn_sched_barrier(0);   // what follows in the program stays behind these loads
 }
 
-// T = threads per row of a first-moment series (row length B = 16 T); NR = 512 / T rows
-template <int T>
-__global__ __launch_bounds__(512) void rows_kernel(RowArgs a)
+// T = threads per row of a first-moment series (row length B = 16 T); NR = THREADS / T rows a workgroup
+template <int T, int THREADS>
+__global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
 {
-    constexpr int NR = 512 / T, T2 = T / 2, B = 16 * T, B2 = 8 * T;
+    constexpr int NR = THREADS / T, T2 = T / 2, B = 16 * T, B2 = 8 * T;
     constexpr int PAD = 16 / NR;   // rows of one bin on different banks when the estimators read
     constexpr int REG1 = Team<T>::REGION + PAD, REG2 = Team<T2>::REGION + PAD;
     constexpr int LDS_ELEMS = (NR * REG1 > 2 * NR * REG2) ? NR * REG1 : 2 * NR * REG2;
@@ -700,6 +700,13 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 namespace godot_spectrum {
 
+#ifndef ROWS_THREADS_1024
+#define ROWS_THREADS_1024 256
+#endif
+#ifndef ROWS_THREADS_512
+#define ROWS_THREADS_512 256
+#endif
+
 // The path takes transforms whose rows have 512, 1 024 or 2 048 points (l = 2^23, 2^24, 2^25) and
 // series that need no wrapping (n <= l/2).
 bool rows_path_applies(int64_t n, int64_t l)
@@ -758,11 +765,13 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
         ra.ngroup = HALF / 4 + 1;
         hipLaunchKernelGGL(rows2048_kernel, dim3((unsigned)(8 + ceil_div(ra.ngroup - 1, 8) * 8)), dim3(512), 0, st, ra);
     } else if (B == 1024) {
-        ra.ngroup = HALF / 8 + 1;
-        hipLaunchKernelGGL(rows_kernel<64>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
+        constexpr int TH = ROWS_THREADS_1024;
+        ra.ngroup = HALF / (TH / 64) + 1;
+        hipLaunchKernelGGL((rows_kernel<64, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
     } else {
-        ra.ngroup = HALF / 16 + 1;
-        hipLaunchKernelGGL(rows_kernel<32>, dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(512), 0, st, ra);
+        constexpr int TH = ROWS_THREADS_512;
+        ra.ngroup = HALF / (TH / 32) + 1;
+        hipLaunchKernelGGL((rows_kernel<32, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
     }
 }
 
