@@ -433,10 +433,13 @@ def run_rank(args):
         zspan = float(zs['ti'][-1] - zs['ti'][0])
         zf0, zdf = 1e-4, 1.0 / (4 * zspan)
         chunk = 1 << 21
-        zws = torch.empty(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), chunk, 2), dtype=torch.uint8,
-                          device=dev)
         kernel_ms = []
         j0_mine, n_mine = gd.frequency_shard(args.nfreq, rank, world)
+        # the workspace of a launch is not monotonic in its number of frequencies (fewer frequencies are
+        # split over more groups of photons): sized for the full launches and for the last, shorter one
+        zneed = max(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), nn_, 2)
+                    for nn_ in {chunk, n_mine % chunk or chunk, min(chunk, max(n_mine, 1))})
+        zws = torch.empty(zneed, dtype=torch.uint8, device=dev)
         zbuf = torch.empty(n_mine, dtype=torch.float64, device=dev)
 
         def search_fn(j0, n):
@@ -516,6 +519,35 @@ def run_rank(args):
                                       sharding='the five transforms dealt over the ranks (dist.transform_shard), '
                                                'cut transforms all-gathered, estimators on every rank')
         del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
+        torch.cuda.empty_cache()
+        # (4) C5: 256 sources x 1e6 photons dealt round-robin over the ranks; every rank runs its
+        # sources as one job (core.run_sources, tables built inside) and the per-source summaries
+        # are all-gathered.  The sources are made before the clock starts.
+        nsrc5 = 256
+        mine5 = gd.source_shard(nsrc5, rank, world)
+        made5 = [core.Data(s_['ti'], s_['we'], s_['TSTART'], s_['TSTOP'], s_['LIVETIME'], s_['exposure'], device=dev)
+                 for s_ in synth.synth_sources_device(nsrc5, dev, years=args.years, indices=mine5)]
+        core.pack_sources(made5)
+
+        def c5_step():
+            for d_ in made5:
+                d_._checkpoints = None
+            return gd.run_sources_sharded(nsrc5, lambda idx: made5, 86400., 300.)
+
+        c5_step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        summ5, _ = c5_step()
+        torch.cuda.synchronize()
+        barrier()
+        t_c5 = max_over_ranks(time.perf_counter() - t0)
+        extra['strong_c5_sources'] = dict(sources=nsrc5, sources_on_rank0=len(mine5), n_gpus=world, s=t_c5,
+                                          sources_per_s=nsrc5 / t_c5,
+                                          largest_p1_first_four=[float(x) for x in summ5[:4, 1]],
+                                          sharding='sources dealt round-robin (dist.source_shard), every rank runs its '
+                                                   'own as one job, 64-byte summaries all-gathered')
+        del made5
         torch.cuda.empty_cache()
 
     if rank != 0:
@@ -670,7 +702,7 @@ def run_rank(args):
                                   elapsed * 1e3),
                    'fits_timed': nfit, 'repeats_per_step': reps,
                    'parallelism': 'every GPU fits its own photon lists, no collective in the timed steps '
-                                  '(extra.strong_c2_fit, extra.strong_c4_z2m, extra.strong_c3_fft: one job split over the GPUs, '
+                                  '(extra.strong_c2_fit, extra.strong_c4_z2m, extra.strong_c3_fft, extra.strong_c5_sources: one job split over the GPUs, '
                                   'collectives timed)'},
         'roofline': roofline,
         'cpu_baseline': cpu,

@@ -30,14 +30,15 @@ def synth(nph, years=10., seed=7):
                 exposure=exposure, S=S, B=B, E=E)
 
 
-def synth_sources_device(nsrc, device, nph=1_000_000, years=10., seed=1000):
+def synth_sources_device(nsrc, device, nph=1_000_000, years=10., seed=1000, indices=None):
     """Many sources over ONE spacecraft file, made on the GPU (a thousand host-made sources
     take minutes): TSTART, TSTOP, LIVETIME as synth() makes them, shared by all sources; every
     source has its own exposure column (that of synth() times 1 + k / 1000: its own sky
     position), photons drawn in proportion to exposure (uniform inside their row) and weights
     clip(u^3.3, 1e-6, 1 - 1e-6), u uniform: mostly background with a tail of source photons,
     like the Beta(0.3, 1.5) of synth().  Returns a list of dicts of device tensors with the
-    keys of synth() (without the totals)."""
+    keys of synth() (without the totals).  indices: make only these of the nsrc sources (a
+    rank's share of a job dealt over several GPUs); source k is the same whoever makes it."""
     import torch
     base = synth(1, years=years, seed=seed)
     TSTART, TSTOP, LIVETIME, exposure = [torch.from_numpy(base[k]).to(device)
@@ -46,7 +47,7 @@ def synth_sources_device(nsrc, device, nph=1_000_000, years=10., seed=1000):
     cdf = cdf / cdf[-1]
     g = torch.Generator(device=device)
     out = []
-    for k in range(nsrc):
+    for k in (range(nsrc) if indices is None else indices):
         g.manual_seed(seed + k)
         u = lambda: torch.rand(nph, dtype=torch.float64, device=device, generator=g)
         idx = torch.searchsorted(cdf, u()).clamp_(max=cdf.numel() - 1)

@@ -124,6 +124,10 @@ def _worker(rank, world, port, q):
         ps = gd.power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn)
         ok4 = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ps, ref_ps[1:]))
         ok4 = ok4 and made == gd.transform_shard(5) and made == list(range(rank, 5, world))
+        # per-source records of a job dealt round-robin come back in source order on every rank
+        mine = gd.source_shard(7)
+        recs = gd.gather_source_records(7, torch.tensor([[float(i), 10.0 * i] for i in mine]).reshape(-1, 2))
+        ok4 = ok4 and bool(torch.equal(recs, torch.tensor([[float(i), 10.0 * i] for i in range(7)])))
         q.put((rank, ok1, ok2 and ok3 and ok4, (c0, c1), gd.source_shard(7)))
     finally:
         dist.destroy_process_group()
