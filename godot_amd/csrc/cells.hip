@@ -550,135 +550,161 @@ __global__ __launch_bounds__(256) void profile_quantiles_kernel(const double *do
     }
 }
 
-// The same for profiles of at most 256 points (the light curves use 200 and 100): lane l
-// keeps points 4l .. 4l+3 in registers, adds its own trapezoids serially and the wavefront
-// scans the 64 lane totals once, where the kernel above scans every chunk of 64 points and
-// stages the row in LDS.  Same results up to the order of the additions.
+// The same for profiles of at most 256 points (the light curves use 200 and 100): FOUR rows a
+// wavefront, a row of sixteen lanes (one DPP row) each.  Lane p of a row keeps points
+// PPL p .. PPL p + PPL - 1 in registers (PPL = 7, 13, 16 for rows of up to 112, 208, 256 points),
+// adds its own trapezoids serially, and the sixteen lane totals are scanned by DPP shifts inside
+// the row: every cross-lane step serves four rows, all lanes hold points (a wavefront per row of
+// 200 points left 14 lanes idle and spent 256 exponentials on it), and the kernel, which is
+// bound by its arithmetic and not by the bytes it reads, takes half the instructions a row.
+// The four rows (contiguous in memory) are fetched with consecutive lanes on consecutive
+// numbers and turned through LDS.  Same results as the kernel above up to the order of the
+// additions.
 // LINSPACE: the abscissae of a row are numpy.linspace(first, last, npt) of its ends to the bit
 // (what the profile kernels write): only the two ends are read, the row's abscissae are formed
 // as those kernels form them, and the kernel moves half the bytes.
-template <bool LINSPACE>
-__global__ __launch_bounds__(256) void profile_quantiles4_kernel(const double *dom, const double *cod,
-                                                                 int64_t ncell, int npt, double c_lo,
-                                                                 double c_hi, double *aguess,
-                                                                 double *xlo, double *xhi)
+constexpr int PQ16_ROWS = 16;    // rows a workgroup of 256 threads
+template <int PPL, bool LINSPACE>
+__global__ __launch_bounds__(256) void profile_quantiles16_kernel(const double *dom, const double *cod,
+                                                                  int64_t ncell, int npt, double c_lo,
+                                                                  double c_hi, double *aguess,
+                                                                  double *xlo, double *xhi)
 {
-    const int lane = threadIdx.x % WAVE;
-    const int64_t cell = (int64_t)blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-    if (cell >= ncell) return;                  // whole wavefronts leave together
-    const double *dp = dom + cell * npt;
-    const double *cp = cod + cell * npt;
-    const int i0 = 4 * lane;
+    extern __shared__ double sm[];   // per wave: cod of four rows (+ dom of four rows unless LINSPACE)
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int q = lane >> 4, p = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * PQ16_ROWS + wave * 4;
+    if (row0 >= ncell) return;                  // whole wavefronts leave together
+    const int nrow = ncell - row0 < 4 ? (int)(ncell - row0) : 4;
+    const int per = LINSPACE ? 1 : 2;
+    double *s_cod = sm + (size_t)wave * per * 4 * npt;
+    double *s_dom = s_cod + 4 * npt;
+    for (int i = lane; i < nrow * npt; i += WAVE) {
+        s_cod[i] = cod[row0 * npt + i];
+        if (!LINSPACE) s_dom[i] = dom[row0 * npt + i];
+    }
+    // the slice belongs to this wavefront alone and LDS serves a wavefront's accesses in
+    // order: only the compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool have = q < nrow;
+    const int64_t cell = row0 + (have ? q : 0);
+    const double *cp = s_cod + (have ? q : 0) * npt;
+    const double *dp = s_dom + (have ? q : 0) * npt;
+    const int i0 = PPL * p;
     const int nseg = npt - 1;
-    double d[5], pdf[5];
-    double best = -INFINITY;
-    int ibest = npt;
     double first = 0.0, last = 0.0, step = 0.0;
     if (LINSPACE) {
-        first = dp[0];
-        last = dp[npt - 1];
+        first = dom[cell * npt];
+        last = dom[cell * npt + npt - 1];
         step = (last - first) / (double)(npt - 1);
     }
+    auto abscissa = [&](int i) {
+        const int ii = i < npt ? i : npt - 1;
+        return LINSPACE ? grid_point(first, last, step, ii, npt) : dp[ii];
+    };
+    // this lane's points: pdf = exp(cod), the first maximum of cod, the trapezoids
+    double pdf[PPL + 1];
+    double best = -INFINITY;
+    int ibest = npt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PPL; ++k) {
         const int i = i0 + k;
         const bool in = i < npt;
-        const int ii = in ? i : npt - 1;
-        const double v = cp[ii];
-        d[k] = LINSPACE ? grid_point(first, last, step, ii, npt) : dp[ii];
+        const double v = cp[in ? i : npt - 1];
         pdf[k] = in ? exp(v) : 0.0;
         if (in && v > best) {
             best = v;
             ibest = i;
         }
     }
-    // the first maximum of the row: the largest value, then the smallest index that holds it
-    // (DPP reductions; a NaN is never a lane's best)
     {
-        const double gbest = team_max<WAVE>(best);
-        ibest = team_min_i32<WAVE>(best == gbest ? ibest : npt);
+        // (DPP reductions inside the row of sixteen lanes; a NaN is never a lane's best)
+        const double gbest = team_max<16>(best);
+        ibest = team_min_i32<16>(best == gbest ? ibest : npt);
     }
-    // point 4l+4 belongs to the next lane: the neighbour inside a row of sixteen lanes by DPP,
-    // across the rows' ends through the scalar unit
+    pdf[PPL] = dpp_f64<0x101>(pdf[0]);          // row_shl:1: the next lane's first point (0 past the row's end)
+    // inclusive sums of this lane's trapezoids: s[k] = seg(i0) + ... + seg(i0 + k)
+    double s[PPL];
+    double run = 0.0;
     {
-        const int row = lane >> 4;
-        const double p16 = lane_f64(pdf[0], 16), p32 = lane_f64(pdf[0], 32), p48 = lane_f64(pdf[0], 48);
-        pdf[4] = dpp_f64<0x101>(pdf[0]);                       // row_shl:1
-        if ((lane & 15) == 15) pdf[4] = row == 0 ? p16 : (row == 1 ? p32 : p48);
-        if (LINSPACE) {
-            const int i4 = i0 + 4 < npt ? i0 + 4 : npt - 1;
-            d[4] = grid_point(first, last, step, i4, npt);
-        } else {
-            const double d16 = lane_f64(d[0], 16), d32 = lane_f64(d[0], 32), d48 = lane_f64(d[0], 48);
-            d[4] = dpp_f64<0x101>(d[0]);
-            if ((lane & 15) == 15) d[4] = row == 0 ? d16 : (row == 1 ? d32 : d48);
+        double dk = abscissa(i0);
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int i = i0 + k;
+            const double dn = abscissa(i + 1);
+            if (i < nseg) run += (dn - dk) * (pdf[k + 1] + pdf[k]) / 2.0;
+            s[k] = run;
+            dk = dn;
         }
     }
-    // inclusive sums of this lane's trapezoids: s[k] = seg(i0) + ... + seg(i0 + k)
-    double s[4];
-    double run = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k;
-        if (i < nseg) run += (d[k + 1] - d[k]) * (pdf[k + 1] + pdf[k]) / 2.0;
-        s[k] = run;
-    }
-    // running sum of the lane totals: inside rows of sixteen lanes by DPP shifts (zeros come in
-    // at a row's start), then the totals of the rows before a lane's own.
-    // cdf[i0] = before: the sum of the lanes below; cdf[i0 + k + 1] = before + s[k]
+    // running sum of the lane totals inside the row (zeros come in at its start);
+    // cdf[i0] = before, cdf[i0 + k + 1] = before + s[k]
     double inrow = run;
-    inrow += dpp_f64<0x111>(inrow);                            // row_shr:1, 2, 4, 8
+    inrow += dpp_f64<0x111>(inrow);             // row_shr:1, 2, 4, 8
     inrow += dpp_f64<0x112>(inrow);
     inrow += dpp_f64<0x114>(inrow);
     inrow += dpp_f64<0x118>(inrow);
-    const double r0 = lane_f64(inrow, 15), r1 = lane_f64(inrow, 31), r2 = lane_f64(inrow, 47),
-                 r3 = lane_f64(inrow, 63);
-    const int row = lane >> 4;
-    const double rows_before = row == 0 ? 0.0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2));
-    const double before = dpp_f64<0x111>(inrow) + rows_before;
-    const double total = ((r0 + r1) + r2) + r3;
+    const double before = dpp_f64<0x111>(inrow);
+    const double total = __shfl(inrow, 15, 16);
     const double inv = 1. / total;
     const double conf[2] = {c_lo, c_hi};
     double res[2];
     double ag = qnan();
-    {
-        // dom[ibest] sits in lane ibest / 4
-        const int src = ibest < npt ? ibest / 4 : 0;
-        const int kk = ibest & 3;
-        const double mine = kk == 0 ? d[0] : (kk == 1 ? d[1] : (kk == 2 ? d[2] : d[3]));
-        const double v = lane_f64(mine, src);                 // src is the same in every lane
-        if (ibest < npt) ag = v;
-    }
+    if (ibest < npt) ag = abscissa(ibest);      // every lane of the row forms it (or reads it from LDS)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        // searchsorted(cdf, conf) (side='left'): the first index whose cdf reaches conf
-        int kfirst = 4;
+    for (int c = 0; c < 2; ++c) {
+        // searchsorted(cdf, conf) (side='left'): the first index whose cdf reaches conf; this
+        // lane's first such point, with the cdf at it and before it
+        int kfirst = PPL;
+        double chi = 0.0, clo = 0.0;
 #pragma unroll
-        for (int k = 3; k >= 0; --k)
-            if (i0 + k < nseg && (before + s[k]) * inv >= conf[q]) kfirst = k;
-        const unsigned long long m = __ballot(kfirst < 4 ? 1 : 0);
-        double r = qnan();
-        const bool at0 = (0.0 * inv >= conf[q]);              // cdf[0] = 0 reaches it: index 0, no interval
-        if (m != 0 && !at0) {
-            const int src = __builtin_ctzll(m);
-            double mine = qnan();
-            if (kfirst < 4) {
-                const double chi = (before + (kfirst == 0 ? s[0] : kfirst == 1 ? s[1] : kfirst == 2 ? s[2] : s[3])) * inv;
-                const double clo = (kfirst == 0 ? before : before + (kfirst == 1 ? s[0] : kfirst == 2 ? s[1] : s[2])) * inv;
-                const double dhi = kfirst == 0 ? d[1] : kfirst == 1 ? d[2] : kfirst == 2 ? d[3] : d[4];
-                const double dlo = kfirst == 0 ? d[0] : kfirst == 1 ? d[1] : kfirst == 2 ? d[2] : d[3];
-                const double slope = (chi - clo) / (dhi - dlo);
-                mine = dlo + (conf[q] - clo) / slope;
+        for (int k = PPL - 1; k >= 0; --k) {
+            const double ck = (before + s[k]) * inv;
+            if (i0 + k < nseg && ck >= conf[c]) {
+                kfirst = k;
+                chi = ck;
+                clo = (k == 0 ? before : before + s[k > 0 ? k - 1 : 0]) * inv;
             }
-            r = lane_f64(mine, src);
         }
-        res[q] = r;
+        const unsigned long long m = __ballot(kfirst < PPL ? 1 : 0);
+        const unsigned mine_row = (unsigned)(m >> (16 * q)) & 0xffffu;
+        double r = qnan();
+        const bool at0 = (0.0 * inv >= conf[c]);              // cdf[0] = 0 reaches it: index 0, no interval
+        double mine = qnan();
+        if (kfirst < PPL) {
+            const double dlo = abscissa(i0 + kfirst), dhi = abscissa(i0 + kfirst + 1);
+            const double slope = (chi - clo) / (dhi - dlo);
+            mine = dlo + (conf[c] - clo) / slope;
+        }
+        const int src = mine_row ? __builtin_ctz(mine_row) : 0;
+        const double got = __shfl(mine, src, 16);
+        if (mine_row != 0 && !at0) r = got;
+        res[c] = r;
     }
-    if (lane == 0) {
+    if (have && p == 0) {
         aguess[cell] = ag;
         xlo[cell] = res[0];
         xhi[cell] = res[1];
     }
+}
+
+template <bool LINSPACE>
+void launch_quantiles16(const double *dom, const double *cod, int64_t ncell, int npt, double c_lo, double c_hi,
+                        double *aguess, double *xlo, double *xhi, hipStream_t st)
+{
+    const dim3 grid((unsigned)ceil_div(ncell, (int64_t)PQ16_ROWS));
+    const size_t smem = (size_t)(256 / WAVE) * (LINSPACE ? 1 : 2) * 4 * npt * sizeof(double);
+    if (npt <= 16 * 7)
+        hipLaunchKernelGGL((profile_quantiles16_kernel<7, LINSPACE>), grid, dim3(256), smem, st, dom, cod, ncell, npt,
+                           c_lo, c_hi, aguess, xlo, xhi);
+    else if (npt <= 16 * 13)
+        hipLaunchKernelGGL((profile_quantiles16_kernel<13, LINSPACE>), grid, dim3(256), smem, st, dom, cod, ncell, npt,
+                           c_lo, c_hi, aguess, xlo, xhi);
+    else
+        hipLaunchKernelGGL((profile_quantiles16_kernel<16, LINSPACE>), grid, dim3(256), smem, st, dom, cod, ncell, npt,
+                           c_lo, c_hi, aguess, xlo, xhi);
 }
 
 // rows 1..5 of get_raw_lightcurve (core.py:1318-1334)
@@ -966,8 +992,7 @@ extern "C" int godot_profile_quantiles(const double *dom, const double *cod, int
     size_t smem = (size_t)4 * 3 * npt * sizeof(double);
     dim3 grid((unsigned)ceil_div(ncell, 4));
     if (npt <= 256)
-        hipLaunchKernelGGL(profile_quantiles4_kernel<false>, grid, dim3(256), 0, st, dom, cod, ncell, npt,
-                           conf_lo, conf_hi, aguess, xlo, xhi);
+        launch_quantiles16<false>(dom, cod, ncell, npt, conf_lo, conf_hi, aguess, xlo, xhi, st);
     else
         hipLaunchKernelGGL(profile_quantiles_kernel, grid, dim3(256), smem, st, dom, cod, ncell, npt,
                            conf_lo, conf_hi, aguess, xlo, xhi);
@@ -987,8 +1012,7 @@ extern "C" int godot_profile_quantiles_linspace(const double *dom, const double 
     if (ncell == 0) return GODOT_OK;
     GODOT_REQUIRE(dom && cod && aguess && xlo && xhi, GODOT_E_INVALID,
                   "godot_profile_quantiles_linspace: null argument");
-    hipLaunchKernelGGL(profile_quantiles4_kernel<true>, dim3((unsigned)ceil_div(ncell, 4)), dim3(256), 0,
-                       (hipStream_t)stream, dom, cod, ncell, npt, conf_lo, conf_hi, aguess, xlo, xhi);
+    launch_quantiles16<true>(dom, cod, ncell, npt, conf_lo, conf_hi, aguess, xlo, xhi, (hipStream_t)stream);
     GODOT_LAUNCH_CHECK("godot_profile_quantiles_linspace");
     return GODOT_OK;
 }
