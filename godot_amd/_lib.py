@@ -78,6 +78,7 @@ SIGNATURES = {
     'godot_bin_sources': (c_int, [ctypes.c_void_p, c_i64, c_i64] + [c_f64p] * 6 + [c_i64p] * 3
                           + [c_ws, c_size, c_stream]),
     'godot_cell_moments': (c_int, _CELLS + [c_i64, c_f64p, c_f64p, c_stream]),
+    'godot_cell_series': (c_int, _CELLS + [c_f64p, c_i64] + [c_f64p] * 6 + [c_stream]),
     'godot_select_workspace_bytes': (c_size, [c_i64]),
     'godot_select_cells': (c_int, [c_f64p, c_i64, c_f64, c_i64p, c_i64p, c_ws, c_size, c_stream]),
     'godot_select_cells_static_max': (c_i64, []),

@@ -1765,8 +1765,12 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
 
     for at in range(0, len(sources), chunk):
         part = sources[at:at + chunk]
-        made = _timeseries_columns(part, tstart, tstop, tcell_ps, False, True, compact_tables)
-        if made is None:
+        spans = None
+        if not any(d.sexposure is not None for d in part):
+            spans = [d._uniform_cells(tstart, tstop, tcell_ps, True) for d in part]
+            if any(not tc > 0 or nc < 1 for _, _, tc, nc in spans):
+                spans = None
+        if spans is None:
             # sources the batched binning does not take: one call after the other
             for d in part:
                 ser = d.get_cells(tstart=tstart, tstop=tstop, tcell=tcell_ps, trim_zero_exposure=False,
@@ -1780,12 +1784,13 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
                     spectra.append((l, tsamp, p0, p1, pb))
             lap('spectra')
             continue
-        cols, off, spans = made
-        sexp, bexp, counts, W, WW = cols[3], cols[4], cols[5], cols[6], cols[7]
-        # the series power_spectrum_fft derives (core.py:2654-2661), for all sources of the chunk at once
-        cf = counts.to(F64)
-        Wb = cf - W
-        WbWb = cf - 2 * W + WW
+        # the bins of all sources of the chunk from three launches, the six series that
+        # power_spectrum_fft transforms (core.py:2178-2183, 241-244, 2654-2661) from one more
+        desc = _batch_descriptors(part, spans, compact_tables)
+        _, _, exp, sexp, bexp, _, lo, hi, _ = ops.bin_sources(desc, want_edges=False)
+        W, WW, Wb, WbWb = ops.cell_series(_joined([d.we for d in part]), lo, hi, exp, sexp, bexp)
+        off = np.concatenate([[0], np.cumsum([sp[3] for sp in spans])]).astype(np.int64)
+        del exp, lo, hi
         lap('time_series')
         # padded length of every source's transform, as power_spectrum_fft chooses it (core.py:2667-2671)
         ls, samp = [], []
@@ -1823,7 +1828,7 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
             peaks.append(torch.stack([m.values, m.indices.to(F64)], 1))
         # (what the side streams read and wrote belongs to this stream's allocator; join() made
         # this stream wait for them, so it may be handed out again from here on)
-        del cols, cf, Wb, WbWb, buf
+        del W, WW, Wb, WbWb, sexp, bexp, buf
         lap('spectra')
     pk = torch.cat(peaks).cpu().numpy()           # the one read of the job
     lap('read_back')

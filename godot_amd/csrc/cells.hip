@@ -210,6 +210,42 @@ __global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *w
     }
 }
 
+// The series power_spectrum_fft transforms, from the bins of a time series (core.py:2178-2183,
+// 241-244, 279-285, 2654-2661): weight moments W, WW of every bin, emptied where the bin has no
+// exposure (as are its source and background exposures, in place), and the background moments
+// Wb = counts - W, WbWb = counts - 2 W + WW, each difference rounded as numpy rounds it.
+template <int T, int R>
+__global__ __launch_bounds__(256) void cell_series_kernel(CellArgs p, const double *exp, double *sexp, double *bexp,
+                                                          double *W, double *WW, double *Wb, double *WbWb)
+{
+    int64_t cell, lo, n;
+    int lane;
+    double S, B;
+    bool bad;
+    p.S = exp;    // unused by cell_setup's callers here; keeps its loads in bounds
+    p.B = nullptr;
+    if (!cell_setup<T>(p, cell, lane, lo, n, S, B, bad)) return;
+    CellData<T, R> cd;
+    cd.load(p.we + lo, n, lane, false);
+    double acc[2];
+    cd.template sums<2>([](double w, double (&s)[2]) {
+        s[0] += w;
+        s[1] += w * w;
+    }, acc);
+    if (lane == 0) {
+        double w1 = bad ? qnan() : acc[0], w2 = bad ? qnan() : acc[1], cnt = (double)n;
+        if (!(exp[cell] > 0)) {          // minimum_exposure = 0: NaN exposure empties the bin too
+            w1 = w2 = cnt = 0.0;
+            sexp[cell] = 0.0;
+            bexp[cell] = 0.0;
+        }
+        W[cell] = w1;
+        WW[cell] = w2;
+        Wb[cell] = __dsub_rn(cnt, w1);
+        WbWb[cell] = __dadd_rn(__dsub_rn(cnt, __dmul_rn(2.0, w1)), w2);
+    }
+}
+
 template <int T, int R>
 __global__ __launch_bounds__(256) void cell_beta_kernel(CellArgs p, const double *alpha, double alpha0,
                                                         const double *guess, double guess0,
@@ -905,6 +941,22 @@ extern "C" int godot_cell_moments(const double *we, int64_t nph, const int64_t *
     CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, 0};
     DISPATCH_TEAM(pick_team(nph, ncell), cell_moments_kernel, 0, p, wsum, w2sum);
     GODOT_LAUNCH_CHECK("godot_cell_moments");
+    return GODOT_OK;
+}
+
+extern "C" int godot_cell_series(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                                 const double *exp, int64_t ncell, double *sexp, double *bexp, double *W,
+                                 double *WW, double *Wb, double *WbWb, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    int rc = check_cells(we, nph, lo, hi, ncell, "godot_cell_series");
+    if (rc) return rc;
+    if (ncell == 0) return GODOT_OK;
+    GODOT_REQUIRE(exp && sexp && bexp && W && WW && Wb && WbWb, GODOT_E_INVALID, "godot_cell_series: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, 0};
+    DISPATCH_TEAM(pick_team(nph, ncell), cell_series_kernel, 0, p, exp, sexp, bexp, W, WW, Wb, WbWb);
+    GODOT_LAUNCH_CHECK("godot_cell_series");
     return GODOT_OK;
 }
 

@@ -257,6 +257,23 @@ def cell_moments(we, lo, hi):
 # ---------------------------------------------------------------------------
 # binning
 # ---------------------------------------------------------------------------
+def cell_series(we, lo, hi, exp, sexp, bexp):
+    """The series power_spectrum_fft transforms, from the bins of a time series: returns
+    (W, WW, Wb, WbWb); bins without exposure are emptied, and sexp / bexp are zeroed there IN
+    PLACE (what CellTimeSeries does to them)."""
+    for t, nm, dt in ((we, 'we', F64), (lo, 'lo', I64), (hi, 'hi', I64), (exp, 'exp', F64), (sexp, 'sexp', F64),
+                      (bexp, 'bexp', F64)):
+        _dev_check(t, dt, nm)
+    n, dev = lo.numel(), we.device
+    if any(t.numel() != n for t in (hi, exp, sexp, bexp)):
+        raise ValueError('lo, hi, exp, sexp, bexp must have one entry per bin')
+    out = [torch.empty(n, dtype=F64, device=dev) for _ in range(4)]
+    with torch.cuda.device(dev):
+        _lib.call('godot_cell_series', _p(we), we.numel(), _p(lo), _p(hi), _p(exp), n, _p(sexp), _p(bexp),
+                  _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream(dev))
+    return tuple(out)
+
+
 def _workspace(nbytes, dev):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
 
@@ -455,7 +472,7 @@ def exposure_checkpoints(tables):
     return out
 
 
-def bin_sources(sources, deadtime_too=False):
+def bin_sources(sources, deadtime_too=False, want_edges=True):
     """Uniform cells of many sources in two launches.  `sources`: one dict per source with the
     device tensors 'tstart', 'tstop', 'exposure', 'livetime', 'table' (exposure_table of those
     rows) or 'checkpoints' (exposure_checkpoints of them), 'ti' (time-sorted photon times),
@@ -463,7 +480,7 @@ def bin_sources(sources, deadtime_too=False):
     built with them), and the numbers 's_over_e', 'b_over_e', 't0', 'tcell', 'ncell'.
     The cells of the sources follow one another in the outputs, and lo/hi index the
     concatenation of the photon lists.  Returns (starts, stops, exp, sexp, bexp, dead or None,
-    lo, hi, source) over all cells."""
+    lo, hi, source) over all cells; want_edges=False leaves starts, stops and source out (None)."""
     if not sources:
         raise ValueError('no sources')
     dev = sources[0]['ti'].device
@@ -504,9 +521,11 @@ def bin_sources(sources, deadtime_too=False):
         rec[nm] = col[nm]
     f = lambda: torch.empty(cells, dtype=F64, device=dev)
     i = lambda: torch.empty(cells, dtype=I64, device=dev)
-    starts, stops, exp, sexp, bexp = f(), f(), f(), f(), f()
+    starts, stops = (f(), f()) if want_edges else (None, None)
+    exp, sexp, bexp = f(), f(), f()
     dead = f() if deadtime_too else None
-    lo, hi, source = i(), i(), i()
+    lo, hi = i(), i()
+    source = i() if want_edges else None
     ws = _workspace(_lib.lib.godot_bin_sources_workspace_bytes(len(sources), cells), dev)
     with torch.cuda.device(dev):
         _lib.call('godot_bin_sources', rec.ctypes.data, len(sources), cells, _p(starts), _p(stops), _p(exp),

@@ -392,6 +392,19 @@ int godot_cell_moments(const double *we, int64_t nph,
                        int64_t ncell, double *wsum, double *w2sum,
                        godot_stream_t stream);
 
+/* The six series power_spectrum_fft transforms (core.py:2654-2661), from the
+ * bins of a time series in one launch: W[c], WW[c] = the sums of the weights and
+ * of their squares over photons lo[c] .. hi[c]-1 (godot_cell_moments); bins
+ * with exp[c] > 0 false are emptied as CellTimeSeries empties them
+ * (minimum_exposure = 0, core.py:241-244, 279-285): W, WW and the count become
+ * 0 and sexp[c], bexp[c] are set to 0 IN PLACE; Wb = count - W and
+ * WbWb = count - 2 W + WW, rounded operation by operation as numpy rounds them.
+ * What get_cells(time_series_only=True) + the first lines of power_spectrum_fft
+ * do in a dozen passes over the bins.                                          */
+int godot_cell_series(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+                      const double *exp, int64_t ncell, double *sexp, double *bexp,
+                      double *W, double *WW, double *Wb, double *WbWb, godot_stream_t stream);
+
 /* Indices of the cells with exp > threshold in ascending order (the
  * trim_zero_exposure mask, core.py:2110-2122).  n_keep is a device int64.
  * workspace: godot_select_workspace_bytes(ncell).                             */
