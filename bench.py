@@ -498,7 +498,24 @@ def run_rank(args):
         Wb3, WbWb3 = cnt3 - W3, cnt3 - 2 * W3 + WW3
         series3 = [W3 - S3, Wb3 - B3, WW3, WbWb3, W3 - WW3]
 
+        # the four-step form where the ranks divide the columns (a power of two of them): every rank
+        # transforms its columns, an all-to-all (point to point) gives every rank whole rows, the
+        # estimators of a rank's rows are summed over the ranks; else whole transforms are dealt out
+        four_step = world > 1 and ops.power_spectrum_parts_supported(nb3, l3, world)
+        c3_method = ('four-step: columns split, all-to-all of 28 l bytes, rows split, spectra all-reduced'
+                     if four_step else ('one fused call' if world == 1 else
+                                        'whole transforms dealt over the ranks (dist.transform_shard), cut transforms '
+                                        'all-gathered, estimators on every rank'))
+
         def c3_step():
+            if four_step:
+                return gd.power_spectrum_fft_four_step(
+                    W3, WW3, S3, Wb3, WbWb3, B3, l3,
+                    lambda part, nparts: ops.power_spectrum_columns(W3, WW3, S3, Wb3, WbWb3, B3, l3, part, nparts),
+                    lambda v, dc, m0, m1: ops.power_spectrum_rows(v, dc, l3, m0, m1)[:3],
+                    lambda nrows: ops.power_spectrum_part_shapes(l3, 1, nrows))
+            if world == 1:
+                return ops.power_spectrum_fft(W3, WW3, S3, Wb3, WbWb3, B3, l3)[:3]
             return gd.power_spectrum_fft_sharded(lambda i: series3[i], l3, ops.rfft,
                                                  lambda *parts: ops.power_spectrum_from_parts(*parts))
 
@@ -513,11 +530,10 @@ def run_rank(args):
         barrier()
         t_c3 = max_over_ranks(time.perf_counter() - t0) / 5
         extra['strong_c3_fft'] = dict(ms=t_c3 * 1e3, nbins=nb3, l=l3, n_gpus=world,
-                                      transforms_on_rank0=len(gd.transform_shard(5, rank, world)),
-                                      gathered_MB=5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0,
-                                      p0_at_bin_1=float(p3[0][1]),
-                                      sharding='the five transforms dealt over the ranks (dist.transform_shard), '
-                                               'cut transforms all-gathered, estimators on every rank')
+                                      exchanged_MB=(16.0 * (l3 + 3 * l3 // 4) * (world - 1) / world / 1e6
+                                                    if four_step else (5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0)),
+                                      p0_at_bin_1=float(p3[0][1]), p1_at_bin_1000=float(p3[1][1000]),
+                                      sharding=c3_method)
         del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
         torch.cuda.empty_cache()
         # (4) C5: 256 sources x 1e6 photons dealt round-robin over the ranks; every rank runs its

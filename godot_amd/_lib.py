@@ -89,6 +89,12 @@ SIGNATURES = {
     'godot_rfft_workspace_bytes': (c_size, [c_i64]),
     'godot_rfft_f64': (c_int, [c_f64p, c_i64, c_i64, c_f64p, c_ws, c_size, c_stream]),
     'godot_power_spectrum_workspace_bytes': (c_size, [c_i64]),
+    'godot_power_spectrum_parts_supported': (c_int, [c_i64, c_i64, c_int]),
+    'godot_power_spectrum_part_rows': (c_i64, []),
+    'godot_power_spectrum_part_bytes': (c_size, [c_i64, c_int]),
+    'godot_power_spectrum_part_workspace_bytes': (c_size, [c_i64, c_int]),
+    'godot_power_spectrum_columns': (c_int, [c_f64p] * 6 + [c_i64, c_i64, c_int, c_int, c_ws, c_ws, c_size, c_stream]),
+    'godot_power_spectrum_rows': (c_int, [c_ws, c_f64p, c_i64, c_i64, c_i64] + [c_f64p] * 4 + [c_stream]),
     'godot_power_spectrum_fft': (c_int, [c_f64p] * 6 + [c_i64, c_i64] + [c_f64p] * 4
                                  + [c_ws, c_size, c_stream]),
     'godot_power_spectrum_from_parts': (c_int, [c_f64p] * 5 + [c_i64] + [c_f64p] * 4 + [c_stream]),

@@ -735,6 +735,62 @@ extern "C" size_t godot_power_spectrum_workspace_bytes(int64_t l)
     return need;
 }
 
+extern "C" int godot_power_spectrum_parts_supported(int64_t n, int64_t l, int nparts)
+{
+    return godot_spectrum::parts_supported(n, l, nparts) ? 1 : 0;
+}
+
+extern "C" int64_t godot_power_spectrum_part_rows(void) { return godot_spectrum::part_rows(); }
+
+extern "C" size_t godot_power_spectrum_part_bytes(int64_t l, int nparts)
+{
+    if (l <= 0 || nparts < 1) return 0;
+    return 16 * godot_spectrum::part_elements(l, nparts);
+}
+
+extern "C" size_t godot_power_spectrum_part_workspace_bytes(int64_t l, int nparts)
+{
+    if (l <= 0 || nparts < 1) return 0;
+    return godot_spectrum::part_workspace_bytes(l, nparts);
+}
+
+extern "C" int godot_power_spectrum_columns(const double *W, const double *WW, const double *S, const double *Wb,
+                                            const double *WbWb, const double *B, int64_t n, int64_t l, int part,
+                                            int nparts, void *v_part, void *workspace, size_t workspace_bytes,
+                                            godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(godot_spectrum::parts_supported(n, l, nparts), GODOT_E_UNSUPPORTED,
+                  "godot_power_spectrum_columns: n = %lld, l = %lld in %d parts is not served "
+                  "(godot_power_spectrum_parts_supported)", (long long)n, (long long)l, nparts);
+    GODOT_REQUIRE(part >= 0 && part < nparts, GODOT_E_INVALID, "godot_power_spectrum_columns: part %d of %d", part,
+                  nparts);
+    GODOT_REQUIRE(W && WW && S && Wb && WbWb && B && v_part, GODOT_E_INVALID,
+                  "godot_power_spectrum_columns: null argument");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_spectrum::part_workspace_bytes(l, nparts), GODOT_E_WORKSPACE,
+                  "godot_power_spectrum_columns: workspace smaller than godot_power_spectrum_part_workspace_bytes");
+    godot_spectrum::power_spectrum_columns_part(W, WW, S, Wb, WbWb, B, n, l, part, nparts, v_part, workspace,
+                                                (hipStream_t)stream);
+    GODOT_LAUNCH_CHECK("godot_power_spectrum_columns");
+    return GODOT_OK;
+}
+
+extern "C" int godot_power_spectrum_rows(const void *v_rows, const double *dc, int64_t l, int64_t m_first,
+                                         int64_t m_end, double *p0, double *p1, double *pb, double *amps,
+                                         godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(godot_spectrum::parts_supported(1, l, 1), GODOT_E_UNSUPPORTED,
+                  "godot_power_spectrum_rows: l = %lld is not served", (long long)l);
+    GODOT_REQUIRE(m_first >= 0 && m_first < m_end && m_end <= godot_spectrum::part_rows() && m_first % 16 == 0,
+                  GODOT_E_INVALID, "godot_power_spectrum_rows: rows %lld .. %lld (the first a multiple of 16, the "
+                  "last at most %lld)", (long long)m_first, (long long)m_end, (long long)godot_spectrum::part_rows());
+    GODOT_REQUIRE(v_rows && dc && p0 && p1 && pb, GODOT_E_INVALID, "godot_power_spectrum_rows: null argument");
+    godot_spectrum::power_spectrum_rows_part(v_rows, dc, l, m_first, m_end, p0, p1, pb, amps, (hipStream_t)stream);
+    GODOT_LAUNCH_CHECK("godot_power_spectrum_rows");
+    return GODOT_OK;
+}
+
 extern "C" int godot_power_spectrum_fft(const double *W, const double *WW, const double *S, const double *Wb,
                                         const double *WbWb, const double *B, int64_t n, int64_t l, double *p0,
                                         double *p1, double *pb, double *amps, void *workspace,

@@ -179,5 +179,15 @@ size_t rows_path_workspace_bytes(int64_t l);
 void power_spectrum_rows(const double *W, const double *WW, const double *S, const double *Wb, const double *WbWb,
                          const double *B, int64_t n, int64_t l, double *p0, double *p1, double *pb, double *amps,
                          void *workspace, hipStream_t stream);
+// the same transform in parts (columns of one part, then rows of a range), for several GPUs
+bool parts_supported(int64_t n, int64_t l, int nparts);
+int64_t part_rows();
+size_t part_elements(int64_t l, int nparts);
+size_t part_workspace_bytes(int64_t l, int nparts);
+void power_spectrum_columns_part(const double *W, const double *WW, const double *S, const double *Wb,
+                                 const double *WbWb, const double *B, int64_t n, int64_t l, int part, int nparts,
+                                 void *v_part, void *workspace, hipStream_t stream);
+void power_spectrum_rows_part(const void *v_rows, const double *dc, int64_t l, int64_t m_first, int64_t m_end,
+                              double *p0, double *p1, double *pb, double *amps, hipStream_t stream);
 
 }   // namespace godot_spectrum

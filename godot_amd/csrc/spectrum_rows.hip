@@ -209,9 +209,11 @@ struct GatherSeries {
     const double *b;
     int64_t n_in;      // samples
     double *XB;        // [B][nhi * R1]
-    int B;             // columns
+    int B;             // columns taken
     int rr;            // rows kept = nhi * R1
     int wg_end;        // workgroups of this and the earlier series
+    int stride;        // columns of the whole series: sample (r, b) is element stride * r + b
+    int bfirst;        // first column taken
 };
 
 struct GatherArgs {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
     {
         const int col = tid & 31;
         for (int r = tid >> 5; r < GR; r += 8) {
-            const int64_t n = (int64_t)S.B * (r0 + r) + b0 + col;
+            const int64_t n = (int64_t)S.stride * (r0 + r) + S.bfirst + b0 + col;
             double x = 0.0;
             if (n < S.n_in) {
                 x = S.a[n];
@@ -260,9 +262,10 @@ struct ColumnSeries {
     const double *XB;  // [B][nhi * R1]
     int64_t L;         // padded length = ROWS * B
     cplx *V;           // [HALF + 1][B]
-    int B;             // columns
+    int B;             // columns taken (the row length of V)
     int nhi;           // rows r_hi < nhi of sixteen hold samples
     int wg_end;        // workgroups of this and the earlier series
+    int bfirst;        // first column taken: column b of V is column bfirst + b of the series
 };
 
 struct ColumnArgs {
@@ -349,11 +352,12 @@ __global__ __launch_bounds__(NCL *NC *TA, 2) void columns_kernel(ColumnArgs a)
     const int u1 = t % 16, g = t / 16;
     cplx *stage = (cplx *)lds;
     const int s = tid / NC, jw = tid % NC;
-    const int64_t b = b0 + jw;
+    const int64_t b = b0 + jw;             // column of V
+    const int64_t bs = S.bfirst + b;       // column of the series: what the twiddles turn by
     const int64_t L = S.L;
     const double invL = 1.0 / (double)L;       // L is a power of two: exact
     cplx *V = S.V;
-    double xs = -(double)((b * (16 * TA)) & (L - 1)) * invL;       // rows step by 16 TA
+    double xs = -(double)((bs * (16 * TA)) & (L - 1)) * invL;      // rows step by 16 TA
     xs -= rint(xs);
     const cplx step = expi_cycles(xs);
     __syncthreads();   // the staged columns lie across the wavefronts' exchange regions: all transforms are done
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(NCL *NC *TA, 2) void columns_kernel(ColumnArgs a)
     STAMP(0, w, 5);
     {
         // mu = s + TA h < R1/2: row c + 16 mu
-        double x0 = -(double)((b * (c + 16 * s)) & (L - 1)) * invL;
+        double x0 = -(double)((bs * (c + 16 * s)) & (L - 1)) * invL;
         x0 -= rint(x0);
         cplx wv = expi_cycles(x0);
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(NCL *NC *TA, 2) void columns_kernel(ColumnArgs a)
     if (c != 0 && c != 8) {
         // mu = R1/2 + s + TA h: conj -> row (16 - c) + 16 (R1 - 1 - mu); rows step down
         const int row8 = (16 - c) + 16 * (R1 / 2 - 1 - s);
-        double x0 = -(double)((b * row8) & (L - 1)) * invL;
+        double x0 = -(double)((bs * row8) & (L - 1)) * invL;
         x0 -= rint(x0);
         cplx wv = expi_cycles(x0);
         const cplx back{step.x, -step.y};
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NCL *NC *TA, 2) void columns_kernel(ColumnArgs a)
     } else if (c == 0 && s == 0) {
         // row R/2 = 16 * (R1/2): C[R1/2] is the first of the staged upper half
         const cplx z = stage[jw * COL_STAGE];
-        double xh = -(double)((b * HALF) & (L - 1)) * invL;
+        double xh = -(double)((bs * HALF) & (L - 1)) * invL;
         xh -= rint(xh);
         V[(int64_t)HALF * B + b] = cmul(z, expi_cycles(xh));
     }
@@ -445,6 +449,7 @@ struct RowArgs {
     int64_t nk;
     int ngroup;          // workgroups with work
     uint32_t stride2;    // elements from V2[0] to V2[1]
+    int m_first, m_end;  // rows m_first <= m < m_end are transformed; the V arrays begin at row m_first
 };
 
 // `base` is the same for every lane (it stays in scalar registers), `off` the lane's element
@@ -475,14 +480,14 @@ __global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
     const int per = gridDim.x >> 3;
     const int g = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (g >= a.ngroup) return;   // uniform
-    const int m0 = g * NR;
+    const int l0 = g * NR, m0 = a.m_first + l0;     // first row of the group: in the arrays, of the transform
     // roles: a team of T2 threads per row of a second-moment series (two series at once),
     // a team of T threads per row of a first-moment series, and for the estimators row
     // rho = tid % NR (adjacent lanes = adjacent bins) with slot s = tid / NR
     const int vr = tid / T2, t2 = tid % T2, rho2 = vr % NR, ser2 = vr / NR;
     const int rho1 = tid / T, t1 = tid % T;
     const int rho = tid % NR, s = tid / NR;
-    const bool valid2 = m0 + rho2 <= HALF, valid1 = m0 + rho1 <= HALF;
+    const bool valid2 = m0 + rho2 < a.m_end, valid1 = m0 + rho1 < a.m_end;
     const int m = m0 + rho;
     double g3[8], g4[8], g5[8];
     cplx f1[8];
@@ -503,8 +508,8 @@ __global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
     };
 
     STAMP(1, g, 0);
-    row_load<T2>(v, a.V2[0], (uint32_t)ser2 * a.stride2 + (uint32_t)((m0 + rho2) * B2 + t2), valid2);
-    row_load<T2>(nx, a.V2[2], (uint32_t)((m0 + rho2) * B2 + t2), valid2 && ser2 == 0);
+    row_load<T2>(v, a.V2[0], (uint32_t)ser2 * a.stride2 + (uint32_t)((l0 + rho2) * B2 + t2), valid2);
+    row_load<T2>(nx, a.V2[2], (uint32_t)((l0 + rho2) * B2 + t2), valid2 && ser2 == 0);
     STAMP(1, g, 1);
     team_fft16<T2>(v, lds + vr * REG2, t2);
     STAMP(1, g, 2);
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
-    row_load<T>(nx, a.V1[0], (uint32_t)((m0 + rho1) * B + t1), valid1);
+    row_load<T>(nx, a.V1[0], (uint32_t)((l0 + rho1) * B + t1), valid1);
     STAMP(1, g, 3);
     team_fft16<T2>(v, lds + vr * REG2, t2);
     STAMP(1, g, 4);
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
-    row_load<T>(nx, a.V1[1], (uint32_t)((m0 + rho1) * B + t1), valid1);
+    row_load<T>(nx, a.V1[1], (uint32_t)((l0 + rho1) * B + t1), valid1);
     STAMP(1, g, 5);
     team_fft16<T>(v, lds + rho1 * REG1, t1);
     STAMP(1, g, 6);
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(THREADS) void rows_kernel(RowArgs a)
     STAMP(1, g, 7);
     team_fft16<T>(nx, lds + rho1 * REG1, t1);
     STAMP(1, g, 8);
-    if (m > HALF) return;
+    if (m >= a.m_end) return;
     const double S2 = a.dc[0], B2v = a.dc[1], SB = a.dc[2];
     const cplx *reg = lds + rho * REG1;
     int sl = s;
@@ -595,12 +600,12 @@ __global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
         g = (w & 7) * per + (w >> 3);
         if (g >= a.ngroup - 1) return;   // uniform
     }
-    const int m0 = g * NR;
+    const int l0 = g * NR, m0 = a.m_first + l0;     // first row of the group: in the arrays, of the transform
     // a wavefront: row m0 + wr of series (or parity) wh; a thread of the estimators: row
     // rho = tid % 4 with slot s = tid / 4
     const int wave = tid >> 6, lane = tid & 63, wr = wave & 3, wh = wave >> 2;
     const int rho = tid % NR, s = tid / NR;
-    const bool valid = m0 + wr <= HALF;
+    const bool valid = m0 + wr < a.m_end;
     const int m = m0 + rho;
     cplx *mine = lds + wave * REG;
     double g3[8], g4[8], g5[8];
@@ -637,8 +642,8 @@ __global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
     };
 
     STAMP(1, g, 0);
-    row_load<64>(v, a.V2[0], (uint32_t)wh * a.stride2 + (uint32_t)((m0 + wr) * B2 + lane), valid);
-    row_load<64>(nx, a.V2[2], (uint32_t)((m0 + wr) * B2 + lane), valid && wh == 0);
+    row_load<64>(v, a.V2[0], (uint32_t)wh * a.stride2 + (uint32_t)((l0 + wr) * B2 + lane), valid);
+    row_load<64>(nx, a.V2[2], (uint32_t)((l0 + wr) * B2 + lane), valid && wh == 0);
     STAMP(1, g, 1);
     if (valid) team_fft16<64, true>(v, mine, lane);
     __syncthreads();
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
     // even (wh = 0) or odd (wh = 1) samples of the row
-    row_load<128>(nx, a.V1[0], (uint32_t)((m0 + wr) * B + 2 * lane + wh), valid);
+    row_load<128>(nx, a.V1[0], (uint32_t)((l0 + wr) * B + 2 * lane + wh), valid);
     STAMP(1, g, 3);
     if (wh == 0 && valid) team_fft16<64, true>(v, mine, lane);
     __syncthreads();
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = nx[i];
-    row_load<128>(nx, a.V1[1], (uint32_t)((m0 + wr) * B + 2 * lane + wh), valid);
+    row_load<128>(nx, a.V1[1], (uint32_t)((l0 + wr) * B + 2 * lane + wh), valid);
     STAMP(1, g, 5);
     if (valid) team_fft16<64, true>(v, mine, lane);
     __syncthreads();
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(512) void rows2048_kernel(RowArgs a)
     if (valid) team_fft16<64, true>(nx, mine, lane);
     __syncthreads();
     STAMP(1, g, 8);
-    if (m > HALF) return;
+    if (m >= a.m_end) return;
     cplx f2[8];
     combine(f2);
     const double S2 = a.dc[0], B2v = a.dc[1], SB = a.dc[2];
@@ -723,6 +728,61 @@ size_t rows_path_workspace_bytes(int64_t l)
            sizeof(double) * (size_t)(2 * l + 3 * (l / 2));
 }
 
+// Pass A for the columns of part `part` of `nparts` equal parts (all of them: 0 of 1): the regrouped
+// samples go to xb, the stored rows of series i to V[i] ([HALF + 1][columns of the part]); the order of
+// the series: WW, WbWb, W - WW (second moments, l/2 points) then W - S, Wb - B.
+void columns_part(const double *W, const double *WW, const double *S, const double *Wb, const double *WbWb,
+                  const double *Bk, int64_t n, int64_t l, int part, int nparts, cplx *const (&V)[5], double *xb,
+                  hipStream_t st)
+{
+    const int B = (int)(l / ROWS);
+    GatherArgs ga{};
+    ColumnArgs ca{};
+    const double *sa[5] = {WW, WbWb, W, W, Wb};
+    const double *sb[5] = {nullptr, nullptr, WW, S, Bk};
+    int end = 0, gend = 0;
+    for (int i = 0; i < 5; ++i) {
+        const int64_t L = i < 3 ? l / 2 : l;
+        const int Bs = i < 3 ? B / 2 : B;         // columns of the series
+        const int Bp = Bs / nparts;               // columns of the part
+        int nhi = (int)ceil_div(n, L / 16);
+        if (nhi > 16) nhi = 16;
+        end += (Bp / NC) * (9 / NCL);
+        gend += (Bp / GC) * (nhi * R1 / GR);
+        ga.s[i] = GatherSeries{sa[i], sb[i], n, xb, Bp, nhi * R1, gend, Bs, part * Bp};
+        ca.s[i] = ColumnSeries{xb, L, V[i], Bp, nhi, end, part * Bp};
+        xb += (size_t)Bp * nhi * R1;
+    }
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)gend), dim3(256), 0, st, ga);
+    ca.nseries = 5;
+    ca.nwg = end;
+    const unsigned gridA = (unsigned)(ceil_div(end, 8) * 8);
+    hipLaunchKernelGGL(columns_kernel, dim3(gridA), dim3(NCL * NC * TA), 0, st, ca);
+}
+
+// Pass B for rows m_first <= m < m_end: V[i] holds those rows of series i (whole rows), dc the
+// zero-frequency values of the three second-moment series.
+void rows_part(const cplx *const (&V)[5], const double *dc, int64_t l, int m_first, int m_end, double *p0,
+               double *p1, double *pb, double *amps, hipStream_t st)
+{
+    const int B = (int)(l / ROWS);
+    const int nrow = m_end - m_first;
+    RowArgs ra{{V[3], V[4]}, {V[0], V[1], V[2]}, dc, p0, p1, pb, amps, l / 4 + 1, 0, (uint32_t)(V[1] - V[0]),
+               m_first, m_end};
+    if (B == 2048) {
+        ra.ngroup = (int)ceil_div(nrow, 4);
+        hipLaunchKernelGGL(rows2048_kernel, dim3((unsigned)(8 + ceil_div(ra.ngroup - 1, 8) * 8)), dim3(512), 0, st, ra);
+    } else if (B == 1024) {
+        constexpr int TH = ROWS_THREADS_1024;
+        ra.ngroup = (int)ceil_div(nrow, TH / 64);
+        hipLaunchKernelGGL((rows_kernel<64, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
+    } else {
+        constexpr int TH = ROWS_THREADS_512;
+        ra.ngroup = (int)ceil_div(nrow, TH / 32);
+        hipLaunchKernelGGL((rows_kernel<32, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
+    }
+}
+
 void power_spectrum_rows(const double *W, const double *WW, const double *S, const double *Wb, const double *WbWb,
                          const double *Bk, int64_t n, int64_t l, double *p0, double *p1, double *pb, double *amps,
                          void *workspace, hipStream_t st)
@@ -734,45 +794,59 @@ void power_spectrum_rows(const double *W, const double *WW, const double *S, con
     cplx *V1a = (cplx *)ws, *V1b = (cplx *)(ws + sz1);
     cplx *V3 = (cplx *)(ws + 2 * sz1), *V4 = (cplx *)(ws + 2 * sz1 + sz2), *V5 = (cplx *)(ws + 2 * sz1 + 2 * sz2);
     double *dc = (double *)(ws + 2 * sz1 + 3 * sz2);
-
     double *xb = (double *)(ws + 2 * sz1 + 3 * sz2 + 256);
-    GatherArgs ga{};
-    ColumnArgs ca{};
-    const double *sa[5] = {WW, WbWb, W, W, Wb};
-    const double *sb[5] = {nullptr, nullptr, WW, S, Bk};
-    cplx *sv[5] = {V3, V4, V5, V1a, V1b};
-    int end = 0, gend = 0;
-    for (int i = 0; i < 5; ++i) {
-        const int64_t L = i < 3 ? l / 2 : l;
-        const int Bs = i < 3 ? B / 2 : B;
-        int nhi = (int)ceil_div(n, L / 16);
-        if (nhi > 16) nhi = 16;
-        end += (Bs / NC) * (9 / NCL);
-        gend += (Bs / GC) * (nhi * R1 / GR);
-        ga.s[i] = GatherSeries{sa[i], sb[i], n, xb, Bs, nhi * R1, gend};
-        ca.s[i] = ColumnSeries{xb, L, sv[i], Bs, nhi, end};
-        xb += (size_t)Bs * nhi * R1;
-    }
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)gend), dim3(256), 0, st, ga);
-    ca.nseries = 5;
-    ca.nwg = end;
-    const unsigned gridA = (unsigned)(ceil_div(end, 8) * 8);
-    hipLaunchKernelGGL(columns_kernel, dim3(gridA), dim3(NCL * NC * TA), 0, st, ca);
+    cplx *const V[5] = {V3, V4, V5, V1a, V1b};
+    columns_part(W, WW, S, Wb, WbWb, Bk, n, l, 0, 1, V, xb, st);
     hipLaunchKernelGGL(rows_dc_kernel, dim3(1), dim3(256), 0, st, (const cplx *)V3, (const cplx *)V4,
                        (const cplx *)V5, B / 2, dc);
-    RowArgs ra{{V1a, V1b}, {V3, V4, V5}, dc, p0, p1, pb, amps, l / 4 + 1, 0, (uint32_t)(sz2 / sizeof(cplx))};
-    if (B == 2048) {
-        ra.ngroup = HALF / 4 + 1;
-        hipLaunchKernelGGL(rows2048_kernel, dim3((unsigned)(8 + ceil_div(ra.ngroup - 1, 8) * 8)), dim3(512), 0, st, ra);
-    } else if (B == 1024) {
-        constexpr int TH = ROWS_THREADS_1024;
-        ra.ngroup = HALF / (TH / 64) + 1;
-        hipLaunchKernelGGL((rows_kernel<64, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
-    } else {
-        constexpr int TH = ROWS_THREADS_512;
-        ra.ngroup = HALF / (TH / 32) + 1;
-        hipLaunchKernelGGL((rows_kernel<32, TH>), dim3((unsigned)(ceil_div(ra.ngroup, 8) * 8)), dim3(TH), 0, st, ra);
-    }
+    const cplx *const Vc[5] = {V3, V4, V5, V1a, V1b};
+    rows_part(Vc, dc, l, 0, HALF + 1, p0, p1, pb, amps, st);
+}
+
+// ---- the same in parts, for a transform dealt over several GPUs ---------------------------
+// A part of the columns is nparts-th of every series' columns; it must hold whole patches of the
+// regrouping (32 columns) and pairs of pass A's tiles (16 columns).
+bool parts_supported(int64_t n, int64_t l, int nparts)
+{
+    if (!rows_path_applies(n, l) || nparts < 1) return false;
+    const int64_t B2 = l / ROWS / 2;
+    return B2 % nparts == 0 && (B2 / nparts) % GC == 0;
+}
+
+int64_t part_rows() { return HALF + 1; }
+
+// elements (complex numbers) of the five arrays of one part of the columns: 3 second-moment
+// series of B/2 columns and 2 first-moment series of B
+size_t part_elements(int64_t l, int nparts)
+{
+    const size_t B = (size_t)(l / ROWS);
+    return (size_t)(HALF + 1) * (3 * (B / 2) + 2 * B) / (size_t)nparts;
+}
+
+size_t part_workspace_bytes(int64_t l, int nparts)
+{
+    return sizeof(double) * (size_t)(2 * l + 3 * (l / 2)) / (size_t)nparts + 256;
+}
+
+void power_spectrum_columns_part(const double *W, const double *WW, const double *S, const double *Wb,
+                                 const double *WbWb, const double *Bk, int64_t n, int64_t l, int part, int nparts,
+                                 void *v_part, void *workspace, hipStream_t st)
+{
+    const size_t B = (size_t)(l / ROWS);
+    const size_t e2 = (size_t)(HALF + 1) * (B / 2) / (size_t)nparts, e1 = 2 * e2;
+    cplx *base = (cplx *)v_part;
+    cplx *const V[5] = {base, base + e2, base + 2 * e2, base + 3 * e2, base + 3 * e2 + e1};
+    columns_part(W, WW, S, Wb, WbWb, Bk, n, l, part, nparts, V, (double *)workspace, st);
+}
+
+void power_spectrum_rows_part(const void *v_rows, const double *dc, int64_t l, int64_t m_first, int64_t m_end,
+                              double *p0, double *p1, double *pb, double *amps, hipStream_t st)
+{
+    const size_t B = (size_t)(l / ROWS);
+    const size_t e2 = (size_t)(m_end - m_first) * (B / 2), e1 = 2 * e2;
+    const cplx *base = (const cplx *)v_rows;
+    const cplx *const V[5] = {base, base + e2, base + 2 * e2, base + 3 * e2, base + 3 * e2 + e1};
+    rows_part(V, dc, l, (int)m_first, (int)m_end, p0, p1, pb, amps, st);
 }
 
 }   // namespace godot_spectrum

@@ -342,6 +342,78 @@ def power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn, group=None, d
     return estimate_fn(parts[0], parts[1], parts[2], parts[3], parts[4])
 
 
+def four_step_rows(world, rank=None):
+    """Row ranges of the four-step transform: the 8 192 + 1 stored rows in `world` contiguous
+    ranges (the last takes the lone row 8 192).  Returns the list of edges, or (first, end) of
+    `rank`."""
+    half = 8192
+    per = half // world
+    edges = [r * per for r in range(world)] + [half + 1]
+    return edges if rank is None else (edges[rank], edges[rank + 1])
+
+
+def power_spectrum_fft_four_step(W, WW, S, Wb, WbWb, B, l, columns_fn, rows_fn, shapes_fn, group=None,
+                                 gather=True):
+    """ONE power spectrum (core.py:2598-2741) whose transforms are split over the ranks: every
+    rank holds the whole series (they are small: 8 bytes a bin), transforms its share of the
+    COLUMNS of the five series laid out as 16 384 rows (columns_fn), the ranks exchange what
+    they made so that each holds whole ROWS (an all-to-all: 28 l bytes over all ranks, sent
+    point to point), and every rank transforms its rows and forms the estimators of the bins
+    they hold (rows_fn).  With gather=True the three spectra are summed over the ranks
+    (every bin is written by one rank, the others hold zeros there), else every rank returns
+    its own bins.  The work and the bytes a rank moves through its memory go down with the
+    number of ranks, which the replicated variant (power_spectrum_fft_sharded: whole transforms
+    dealt out) cannot offer beyond five ranks and pays for with the full transforms gathered.
+
+    columns_fn(part, nparts) -> (buffer, [five (8193, columns, 2) tensors])   ops.power_spectrum_columns
+    rows_fn(v_rows, dc, m_first, m_end) -> (p0, p1, pb)                        ops.power_spectrum_rows
+    shapes_fn(nrows) -> five (rows, columns) shapes of whole rows              ops.power_spectrum_part_shapes
+    The number of ranks must divide the columns as godot_power_spectrum_parts_supported says
+    (a power of two up to 8 for l = 2^23, up to 32 for l = 2^25)."""
+    rank, world = _world(group)
+    edges = four_step_rows(world)
+    m_first, m_end = edges[rank], edges[rank + 1]
+    _, parts = columns_fn(rank, world)
+    home = parts[0].device
+    dc = torch.stack([WW.sum(), WbWb.sum(), (W - WW).sum()])
+    shapes = shapes_fn(m_end - m_first)
+    v_rows = torch.empty(sum(2 * r * c for r, c in shapes), dtype=parts[0].dtype, device=home)
+    views, at = [], 0
+    for r, c in shapes:
+        views.append(v_rows[at:at + 2 * r * c].view(r, c, 2))
+        at += 2 * r * c
+    if world == 1:
+        for v, p in zip(views, parts):
+            v.copy_(p[m_first:m_end])
+    else:
+        cdev = _device_of(group)
+        peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        todo, pieces = [], []
+        for i, p in enumerate(parts):
+            pc = p.to(cdev)
+            got = []
+            for s_ in range(world):
+                if s_ == rank:
+                    got.append(pc[m_first:m_end])
+                    continue
+                t = torch.empty((m_end - m_first,) + tuple(pc.shape[1:]), dtype=pc.dtype, device=cdev)
+                got.append(t)
+                todo.append(dist.P2POp(dist.irecv, t, peer(s_), group, tag=i))
+                todo.append(dist.P2POp(dist.isend, pc[edges[s_]:edges[s_ + 1]], peer(s_), group, tag=i))
+            pieces.append(got)
+        for req in dist.batch_isend_irecv(todo):
+            req.wait()
+        for v, got in zip(views, pieces):
+            # rank s made columns s * columns / world ...: side by side they are the whole rows
+            v.copy_(torch.cat(got, dim=1).to(home))
+    p0, p1, pb = rows_fn(v_rows, dc, m_first, m_end)
+    if gather and world > 1:
+        both = torch.stack([p0, p1, pb]).to(_device_of(group))
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        p0, p1, pb = (x.to(home) for x in both)
+    return p0, p1, pb
+
+
 def _device_of(group=None):
     """Device of the collectives of this process: the current GPU under nccl, the host under gloo."""
     if dist.is_initialized() and dist.get_backend(group) == 'nccl':

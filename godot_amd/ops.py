@@ -650,6 +650,70 @@ def power_spectrum_fft(W, WW, S, Wb, WbWb, B, l, want_amps=False, out=None, work
     return p0, p1, pb, amps
 
 
+def power_spectrum_parts_supported(n, l, nparts):
+    """Whether power_spectrum_columns / power_spectrum_rows serve a series of n bins padded to l,
+    dealt over nparts GPUs."""
+    return bool(_lib.lib.godot_power_spectrum_parts_supported(int(n), int(l), int(nparts)))
+
+
+def power_spectrum_part_shapes(l, nparts, nrows=None):
+    """Shapes (rows, columns) of the five arrays of complex numbers that one part of the columns
+    (nrows None: all 8 193 stored rows, a nparts-th of the columns) or a range of nrows whole rows
+    (nparts = 1) consists of: WW, WbWb, W - WW, then W - S, Wb - B."""
+    rows = int(_lib.lib.godot_power_spectrum_part_rows()) if nrows is None else int(nrows)
+    B = l // 16384
+    return [(rows, B // 2 // nparts)] * 3 + [(rows, B // nparts)] * 2
+
+
+def _part_views(buf, shapes):
+    out, at = [], 0
+    for r, c in shapes:
+        out.append(buf[at:at + 2 * r * c].view(r, c, 2))
+        at += 2 * r * c
+    return out
+
+
+def power_spectrum_columns(W, WW, S, Wb, WbWb, B, l, part, nparts):
+    """Columns-pass of power_spectrum_fft for part `part` of nparts GPUs.  Returns (buffer,
+    views): one float64 allocation holding the five arrays of this part back to back, and the
+    five (8 193, columns, 2) views of it."""
+    for t, nm in ((W, 'W'), (WW, 'WW'), (S, 'S'), (Wb, 'Wb'), (WbWb, 'WbWb'), (B, 'B')):
+        _dev_check(t, F64, nm)
+        if t.numel() != W.numel():
+            raise ValueError('the six series must have equal lengths')
+    n, dev = W.numel(), W.device
+    if not power_spectrum_parts_supported(n, l, nparts):
+        raise ValueError('a series of %d bins padded to %d is not transformed in %d parts' % (n, l, nparts))
+    shapes = power_spectrum_part_shapes(l, nparts)
+    buf = torch.empty(sum(2 * r * c for r, c in shapes), dtype=F64, device=dev)
+    ws = _workspace(_lib.lib.godot_power_spectrum_part_workspace_bytes(l, nparts), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_power_spectrum_columns', _p(W), _p(WW), _p(S), _p(Wb), _p(WbWb), _p(B), n, l, int(part),
+                  int(nparts), _p(buf), _p(ws), ws.numel(), _stream(dev))
+    return buf, _part_views(buf, shapes)
+
+
+def power_spectrum_rows(v_rows, dc, l, m_first, m_end, want_amps=False):
+    """Rows-pass of power_spectrum_fft for rows m_first .. m_end - 1: v_rows is one float64
+    tensor with the five arrays of whole rows back to back (power_spectrum_part_shapes(l, 1,
+    m_end - m_first)), dc the sums of WW, WbWb and W - WW (device, 3 doubles).  Returns
+    (p0, p1, pb, amps) of l // 4 + 1 bins with the bins of these rows filled and zeros elsewhere."""
+    _dev_check(v_rows, F64, 'v_rows')
+    _dev_check(dc, F64, 'dc')
+    dev = v_rows.device
+    need = sum(2 * r * c for r, c in power_spectrum_part_shapes(l, 1, m_end - m_first))
+    if v_rows.numel() < need or dc.numel() < 3:
+        raise ValueError('v_rows holds %d numbers, rows %d .. %d of l = %d need %d' % (v_rows.numel(), m_first, m_end,
+                                                                                      l, need))
+    nk = l // 4 + 1
+    p0, p1, pb = (torch.zeros(nk, dtype=F64, device=dev) for _ in range(3))
+    amps = torch.zeros((8, nk), dtype=F64, device=dev) if want_amps else None
+    with torch.cuda.device(dev):
+        _lib.call('godot_power_spectrum_rows', _p(v_rows), _p(dc), l, int(m_first), int(m_end), _p(p0), _p(p1), _p(pb),
+                  _p(amps), _stream(dev))
+    return p0, p1, pb, amps
+
+
 def power_spectrum_from_parts(f1, f2, g3, g4, g5, want_amps=False):
     """(p0, p1, pb, amps) of power_spectrum_fft from its five transforms, each an (nk, 2)
     tensor of (re, im): rfft(W - S)[:nk], rfft(Wb - B)[:nk] and the even bins

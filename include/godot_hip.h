@@ -467,6 +467,38 @@ int godot_power_spectrum_fft(const double *W, const double *WW, const double *S,
                              void *workspace, size_t workspace_bytes,
                              godot_stream_t stream);
 
+/* power_spectrum_fft (core.py:2598-2741) dealt over several GPUs: the transform of
+ * godot_power_spectrum_fft for l = 2^23, 2^24, 2^25 is "columns, then rows" of the
+ * series laid out as 16 384 rows (l = 16 384 B points: first the 16 384-point
+ * transforms of the B columns, then, after a twiddle, the B-point transforms of the
+ * rows, of which rows 0 .. 8 192 are kept: the series are real).  Part `part` of
+ * `nparts` GPUs takes its nparts-th of the columns of the five series
+ * (godot_power_spectrum_columns: every GPU holds the whole series), the GPUs
+ * exchange what they made so that each holds whole rows m_first <= m < m_end of all
+ * five (an all-to-all of 28 l bytes in total over all GPUs, the caller's job: RCCL),
+ * and godot_power_spectrum_rows transforms those rows and writes the estimators of
+ * the bins they hold (bins m + 16 384 p and 16 384 - m + 16 384 p; the other entries
+ * of p0, p1, pb are not touched).
+ * v_part: godot_power_spectrum_part_bytes(l, nparts) bytes: five arrays of complex
+ * numbers back to back, [8 193][B / (2 nparts)] for WW, WbWb and W - WW, then
+ * [8 193][B / nparts] for W - S and Wb - B.  v_rows: the same five arrays with whole
+ * rows: [m_end - m_first][B / 2] three times, [m_end - m_first][B] twice.  dc: the
+ * sums of WW, WbWb and W - WW over the series (device, three doubles).  m_first a
+ * multiple of 16.  godot_power_spectrum_parts_supported says for which (n, l,
+ * nparts) this is served: the lengths above, n <= l / 2, B / (2 nparts) a multiple
+ * of 32.  No counterpart in the reference, which transforms on one CPU.          */
+int godot_power_spectrum_parts_supported(int64_t n, int64_t l, int nparts);
+int64_t godot_power_spectrum_part_rows(void);
+size_t godot_power_spectrum_part_bytes(int64_t l, int nparts);
+size_t godot_power_spectrum_part_workspace_bytes(int64_t l, int nparts);
+int godot_power_spectrum_columns(const double *W, const double *WW, const double *S, const double *Wb,
+                                 const double *WbWb, const double *B, int64_t n, int64_t l, int part,
+                                 int nparts, void *v_part, void *workspace, size_t workspace_bytes,
+                                 godot_stream_t stream);
+int godot_power_spectrum_rows(const void *v_rows, const double *dc, int64_t l, int64_t m_first,
+                              int64_t m_end, double *p0, double *p1, double *pb, double *amps,
+                              godot_stream_t stream);
+
 /* The estimators of power_spectrum_fft (core.py:2707-2741) from the five
  * transforms handed over one by one, each an array of nk (re, im) pairs cut to
  * what the estimators read: f1 = rfft(W - S)[:nk], f2 = rfft(Wb - B)[:nk],

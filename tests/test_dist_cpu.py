@@ -124,6 +124,39 @@ def _worker(rank, world, port, q):
         ps = gd.power_spectrum_fft_sharded(series_fn, l, rfft_fn, estimate_fn)
         ok4 = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ps, ref_ps[1:]))
         ok4 = ok4 and made == gd.transform_shard(5) and made == list(range(rank, 5, world))
+        # four-step transform: the exchange puts every rank's columns side by side into whole rows.
+        # Stand-ins for the passes: "columns" hands out slices of known arrays [8193][cols][2],
+        # "rows" checks that it received the right rows of all columns and marks its bins
+        l4 = 1 << 23
+        shapes_all = [(8193, 256)] * 3 + [(8193, 512)] * 2
+        full = [torch.arange(r * c * 2, dtype=torch.float64).reshape(r, c, 2) + 1000.0 * i
+                for i, (r, c) in enumerate(shapes_all)]
+
+        def columns_fn(part, nparts):
+            return None, [f[:, part * (f.shape[1] // nparts):(part + 1) * (f.shape[1] // nparts)].contiguous()
+                          for f in full]
+
+        def shapes_fn(nrows):
+            return [(nrows, c) for _, c in shapes_all]
+
+        seen = {}
+
+        def rows_fn(v_rows, dc, m0, m1):
+            at, ok = 0, True
+            for f in full:
+                n_ = (m1 - m0) * f.shape[1] * 2
+                ok = ok and bool(torch.equal(v_rows[at:at + n_].view(m1 - m0, f.shape[1], 2), f[m0:m1]))
+                at += n_
+            seen['ok'], seen['rows'] = ok and at == v_rows.numel(), (m0, m1)
+            out = torch.zeros(3, 16)
+            out[:, rank] = 1.0 + rank
+            return out[0], out[1], out[2]
+
+        z = torch.zeros(10, dtype=torch.float64)
+        p0_, p1_, pb_ = gd.power_spectrum_fft_four_step(z, z, z, z, z, z, l4, columns_fn, rows_fn, shapes_fn)
+        want = torch.zeros(16)
+        want[0], want[1] = 1.0, 2.0
+        ok4 = ok4 and seen['ok'] and seen['rows'] == gd.four_step_rows(world, rank) and bool(torch.equal(p1_, want))
         # per-source records of a job dealt round-robin come back in source order on every rank
         mine = gd.source_shard(7)
         recs = gd.gather_source_records(7, torch.tensor([[float(i), 10.0 * i] for i in mine]).reshape(-1, 2))

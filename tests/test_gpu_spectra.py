@@ -346,3 +346,50 @@ def test_long_series_transformed_by_columns_and_rows(lg, nbin):
     got = qamps.cpu().numpy()
     sc = np.abs(ramps[:, 1:]).max(axis=1, keepdims=True)
     assert (np.abs(got[:, 1:] - ramps[:, 1:]) <= 1e-8 * sc).all()
+
+
+@pytest.mark.parametrize('lg,nbin,nparts', [(23, 1_051_920, 8), (24, 1_893_456, 4), (25, 3_786_912, 2), (23, 700, 2)])
+def test_transform_in_parts_equals_the_whole(lg, nbin, nparts):
+    """The columns-then-rows transform done part by part on one GPU -- the columns of every part
+    (godot_power_spectrum_columns), the rows of every range (godot_power_spectrum_rows) after the
+    pieces have been put side by side as an all-to-all between GPUs would put them -- gives the
+    bits of godot_power_spectrum_fft for P_0, P_1, P_b up to the zero-frequency sums (formed from
+    the series instead of from row 0: 1e-12), every bin written by exactly one range."""
+    from godot_amd import ops, dist as gd
+    dev = torch.device('cuda:0')
+    l = 1 << lg
+    g = torch.Generator(device=dev)
+    g.manual_seed(lg * 1000 + nparts)
+    cnt = torch.poisson(torch.full((nbin,), 2.6, dtype=torch.float64, device=dev), generator=g)
+    W = cnt * torch.rand(nbin, dtype=torch.float64, device=dev, generator=g) * 0.3
+    WW = W * 0.4
+    S = torch.full((nbin,), float(W.mean()) * 1.1, dtype=torch.float64, device=dev)
+    B = S * 5
+    Wb, WbWb = cnt - W, cnt - 2 * W + WW
+    assert ops.power_spectrum_parts_supported(nbin, l, nparts)
+    assert not ops.power_spectrum_parts_supported(nbin, l, 3) and not ops.power_spectrum_parts_supported(nbin, 1 << 20, 2)
+    whole = ops.power_spectrum_fft(W, WW, S, Wb, WbWb, B, l)[:3]
+    parts = [ops.power_spectrum_columns(W, WW, S, Wb, WbWb, B, l, p, nparts)[1] for p in range(nparts)]
+    dc = torch.stack([WW.sum(), WbWb.sum(), (W - WW).sum()])
+    edges = gd.four_step_rows(nparts)
+    assert edges[0] == 0 and edges[-1] == 8193 and all(e % 16 == 0 for e in edges[:-1])
+    total = [torch.zeros(l // 4 + 1, dtype=torch.float64, device=dev) for _ in range(3)]
+    written = torch.zeros(l // 4 + 1, dtype=torch.int32, device=dev)
+    for r in range(nparts):
+        m0, m1 = edges[r], edges[r + 1]
+        rows = [torch.cat([parts[p][i][m0:m1] for p in range(nparts)], dim=1) for i in range(5)]
+        v_rows = torch.cat([x.reshape(-1) for x in rows])
+        got = ops.power_spectrum_rows(v_rows, dc, l, m0, m1)[:3]
+        for t, x in zip(total, got):
+            t += x
+        written += (got[1] != 0).to(torch.int32)
+    assert int(written.max()) == 1
+    for t, w in zip(total, whole):
+        fin = torch.isfinite(w)
+        assert torch.equal(torch.isfinite(t), fin)
+        scale = w[fin].abs().max()
+        # (a series of a few hundred bins: the estimators near zero frequency are differences of
+        # nearly equal sums, and the last bits of the zero-frequency values show)
+        assert float((t[fin] - w[fin]).abs().max()) <= (1e-12 if nbin > 10_000 else 1e-7) * float(scale)
+    with pytest.raises(Exception):
+        ops.power_spectrum_rows(v_rows[:100], dc, l, edges[-2], edges[-1])
