@@ -502,7 +502,8 @@ def run_rank(args):
         # transforms its columns, an all-to-all (point to point) gives every rank whole rows, the
         # estimators of a rank's rows are summed over the ranks; else whole transforms are dealt out
         four_step = world > 1 and ops.power_spectrum_parts_supported(nb3, l3, world)
-        c3_method = ('four-step: columns split, all-to-all of 28 l bytes, rows split, spectra all-reduced'
+        c3_method = ('four-step: columns split, all-to-all of 28 l bytes, rows split; every rank keeps the bins of its '
+                     'rows (the largest P_1 is all-reduced)'
                      if four_step else ('one fused call' if world == 1 else
                                         'whole transforms dealt over the ranks (dist.transform_shard), cut transforms '
                                         'all-gathered, estimators on every rank'))
@@ -513,7 +514,7 @@ def run_rank(args):
                     W3, WW3, S3, Wb3, WbWb3, B3, l3,
                     lambda part, nparts: ops.power_spectrum_columns(W3, WW3, S3, Wb3, WbWb3, B3, l3, part, nparts),
                     lambda v, dc, m0, m1: ops.power_spectrum_rows(v, dc, l3, m0, m1)[:3],
-                    lambda nrows: ops.power_spectrum_part_shapes(l3, 1, nrows))
+                    lambda nrows: ops.power_spectrum_part_shapes(l3, 1, nrows), gather=False)
             if world == 1:
                 return ops.power_spectrum_fft(W3, WW3, S3, Wb3, WbWb3, B3, l3)[:3]
             return gd.power_spectrum_fft_sharded(lambda i: series3[i], l3, ops.rfft,
@@ -529,10 +530,11 @@ def run_rank(args):
         torch.cuda.synchronize()
         barrier()
         t_c3 = max_over_ranks(time.perf_counter() - t0) / 5
+        p1_max3 = max_over_ranks(float(torch.nan_to_num(p3[1][1:], nan=-np.inf).max().cpu()))
         extra['strong_c3_fft'] = dict(ms=t_c3 * 1e3, nbins=nb3, l=l3, n_gpus=world,
                                       exchanged_MB=(16.0 * (l3 + 3 * l3 // 4) * (world - 1) / world / 1e6
                                                     if four_step else (5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0)),
-                                      p0_at_bin_1=float(p3[0][1]), p1_at_bin_1000=float(p3[1][1000]),
+                                      p0_at_bin_1=float(p3[0][1]), p1_at_bin_1000=float(p3[1][1000]), p1_max=p1_max3,
                                       sharding=c3_method)
         del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
         torch.cuda.empty_cache()
