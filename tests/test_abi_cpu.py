@@ -162,24 +162,29 @@ def test_every_entry_point_rejects_null_pointers_without_a_gpu():
 
 
 def test_source_descriptor_layout_is_the_headers(tmp_path):
-    """ops.SOURCE_CELLS, the numpy record the Python layer fills, has the size and the field
-    offsets that a C compiler gives godot_source_cells of include/godot_hip.h."""
+    """ops.SOURCE_CELLS and ops.EXPOSURE_ROWS, the numpy records the Python layer fills, have the sizes
+    and the field offsets that a C compiler gives godot_source_cells and godot_exposure_rows of
+    include/godot_hip.h."""
     import shutil
     import subprocess
     from godot_amd import ops
     if shutil.which('gcc') is None:
         pytest.skip('no C compiler')
-    names = list(ops.SOURCE_CELLS.names)
+    records = (('godot_source_cells', ops.SOURCE_CELLS), ('godot_exposure_rows', ops.EXPOSURE_ROWS))
     src = tmp_path / 'layout.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "godot_hip.h"\nint main(void){\n'
-                   'printf("%zu\\n", sizeof(godot_source_cells));\n'
-                   + ''.join('printf("%%zu\\n", offsetof(godot_source_cells, %s));\n' % n for n in names)
+                   + ''.join('printf("%%zu\\n", sizeof(%s));\n' % ctype
+                             + ''.join('printf("%%zu\\n", offsetof(%s, %s));\n' % (ctype, n) for n in rec.names)
+                             for ctype, rec in records)
                    + 'return 0;}\n')
     exe = tmp_path / 'layout'
     subprocess.run(['gcc', '-I', os.path.dirname(HEADER), str(src), '-o', str(exe)], check=True)
     out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert out[0] == ops.SOURCE_CELLS.itemsize
-    assert out[1:] == [ops.SOURCE_CELLS.fields[n][1] for n in names]
+    for ctype, rec in records:
+        mine = [rec.itemsize] + [rec.fields[n][1] for n in rec.names]
+        assert out[:len(mine)] == mine, ctype
+        out = out[len(mine):]
+    assert out == []
     # and the call refuses a table it cannot index before any device work
     from godot_amd import _lib
     rec = np.zeros(1, dtype=ops.SOURCE_CELLS)
