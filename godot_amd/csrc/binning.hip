@@ -267,7 +267,9 @@ __global__ __launch_bounds__(SEQ_THREADS) void exposure_cumsum_kernel(ExposureLo
     };
     fetch(0, 0, tid, std::integral_constant<int, SEQ_THREADS>{});
     __syncthreads();
-    double carry = 0.0;   // lanes 0..3 of wave 0: running sum of series `lane`
+    // lanes 0..3 of wave 0: running sum of series `lane`; -0.0 + x = x for every x, so that the
+    // first sum is the first row itself, as numpy.cumsum has it
+    double carry = -0.0;
     for (int64_t t = 0; t < ntile; ++t) {
         const int buf = (int)(t & 1);
         if (tid < 64) {
@@ -350,6 +352,9 @@ __global__ __launch_bounds__(SEQ_THREADS) void exposure_cumsum_kernel(ExposureLo
 //   5. per accepted chunk: the scan inside the chunk from its exact start.
 // A binade is crossed some forty times in a ten-year table, so all but a few
 // dozen chunks per series go the parallel way.
+// (Rows of -0.0 count as +0.0 here: a running sum that numpy would still show
+// as -0.0, because every row so far was -0.0, comes out as +0.0.  The serial
+// sums of short tables keep that sign.)
 // ---------------------------------------------------------------------------
 constexpr int CS_CHUNK = 2048;
 constexpr int CS_THREADS = 256;
@@ -1580,20 +1585,82 @@ __global__ __launch_bounds__(CS_THREADS) void ck_fill_kernel(const CkSource *src
         if (d3) ckd[3] = o3;
     }
 }
-// tables too short for the parallel sums: one wavefront a table, lane c walks series c
-__global__ __launch_bounds__(64) void ck_serial_kernel(const CkSource *src)
+// Tables whose running sums are formed serially, bit for bit as numpy adds them: one wavefront a
+// table.  All 64 lanes fetch a tile of rows (the next tile's loads are in flight while the
+// present one is walked) and lay its four series down in LDS; lanes 0..3 then walk one series
+// each, sixteen rows to a checkpoint, two register batches so that the LDS reads of one are under
+// way while the other goes through the chain of additions.  A wavefront takes a dozen cycles
+// a row (measured: 7 to 11 ns) whatever else the chip does, and a thousand tables are a thousand
+// wavefronts that walk at the same time.
+// The sums start from -0.0 and the rows past the end of a table count as -0.0: s + (-0.0) = s
+// for every s, and -0.0 + x = x for every x, the first row included.
+constexpr int CKW_TILE = 512;
+constexpr int CKW_RPL = CKW_TILE / 64;   // rows of a tile a lane fetches
+__global__ __launch_bounds__(64) void ck_wave_kernel(const CkSource *src)
 {
-    const CkSource &s = src[blockIdx.y];
+    __shared__ __align__(16) double s_x[2][4][CKW_TILE];
+    const CkSource &s = src[blockIdx.x];
     if (s.nchunk > 0) return;   // the parallel steps build this one
-    const int c = threadIdx.x;
-    if (c >= 4) return;
+    const int lane = threadIdx.x;
+    const int64_t n = s.n, ntile = (n + CKW_TILE - 1) / CKW_TILE;
+    const ExposureLoad ld = s.ld;
+    Quad q[CKW_RPL];
+    auto fetch = [&](int64_t tile) {
+        const int64_t base = tile * CKW_TILE;
+#pragma unroll
+        for (int j = 0; j < CKW_RPL; ++j) {
+            const int64_t r = base + lane + 64 * j;
+            q[j] = Quad{-0.0, -0.0, -0.0, -0.0};
+            if (r < n) q[j] = ld(r);
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < CKW_RPL; ++j) {
+            const int k = lane + 64 * j;
+            s_x[buf][0][k] = q[j].a;
+            s_x[buf][1][k] = q[j].b;
+            s_x[buf][2][k] = q[j].c;
+            s_x[buf][3][k] = q[j].d;
+        }
+    };
+    // LDS serves a wavefront's accesses in order: only the compiler has to be kept from reordering
+    auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+    fetch(0);
+    put(0);
+    double sum = -0.0;
     double *out = (double *)s.ck;
-    double sum = 0.0;
-    for (int64_t r = 0; r < s.n; ++r) {
-        const Quad x = s.ld(r);
-        const double v = c == 0 ? x.a : (c == 1 ? x.b : (c == 2 ? x.c : x.d));
-        sum = r ? sum + v : v;
-        if ((r & (CK_ROWS - 1)) == CK_ROWS - 1 || r == s.n - 1) out[(r / CK_ROWS) * 4 + c] = sum;
+    for (int64_t t = 0; t < ntile; ++t) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntile) fetch(t + 1);
+        fence();
+        if (lane < 4) {
+            const double *row = s_x[buf][lane];
+            const int64_t base = t * CKW_TILE;
+            const int m = (int)((n - base) < CKW_TILE ? (n - base) : CKW_TILE);
+            double *o = out + (base / CK_ROWS) * 4 + lane;
+            double a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = row[u];
+            for (int k = 0; k < m; k += 32) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) b[u] = row[k + 16 + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum = __dadd_rn(sum, a[u]);
+                o[(k / CK_ROWS) * 4] = sum;
+                if (k + 32 < CKW_TILE) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a[u] = row[k + 32 + u];
+                }
+                if (k + 16 < m) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum = __dadd_rn(sum, b[u]);
+                    o[(k / CK_ROWS + 1) * 4] = sum;
+                }
+            }
+        }
+        fence();
+        if (t + 1 < ntile) put(buf ^ 1);
     }
 }
 
@@ -1894,12 +1961,18 @@ extern "C" size_t godot_exposure_checkpoints_bytes(int64_t n_ft2)
     return n_ft2 <= 0 ? 0 : align256(sizeof(Quad) * (size_t)ck_records(n_ft2));
 }
 
+// Which way a table's running sums are formed: by the parallel steps from four chunks on, serially
+// by a wavefront of its own below that.  (Measured for tables of 32 440 rows: a thousand of them
+// take 4.3 ms serially and 6.5 ms in parallel, 128 of them 1.09 and 0.89 ms, two 0.42 and 0.25 ms;
+// from 131 072 rows on the parallel steps win whatever the number of tables.)
+static bool ck_parallel(int64_t n) { return n >= 4 * CS_CHUNK; }
+
 extern "C" size_t godot_exposure_checkpoints_workspace_bytes(const godot_exposure_rows *tables, int64_t ntab)
 {
     if (!tables || ntab <= 0) return 0;
     size_t b = align256(sizeof(CkSource) * (size_t)ntab);
     for (int64_t k = 0; k < ntab; ++k)
-        if (tables[k].n_ft2 >= 4 * CS_CHUNK) b += cs_scratch_bytes(tables[k].n_ft2);
+        if (ck_parallel(tables[k].n_ft2)) b += cs_scratch_bytes(tables[k].n_ft2);
     return b;
 }
 
@@ -1935,7 +2008,7 @@ extern "C" int godot_exposure_checkpoints(const godot_exposure_rows *tables, int
         c.info = nullptr;
         c.entry = nullptr;
         c.by_walk = nullptr;
-        if (t.n_ft2 < 4 * CS_CHUNK) {
+        if (!ck_parallel(t.n_ft2)) {
             any_short = true;
             continue;
         }
@@ -1964,7 +2037,7 @@ extern "C" int godot_exposure_checkpoints(const godot_exposure_rows *tables, int
         const int64_t nt = ntab - first < MAX_Y ? ntab - first : MAX_Y;
         const unsigned ny = (unsigned)nt;
         const CkSource *d = d_src + first;
-        if (any_short) hipLaunchKernelGGL(ck_serial_kernel, dim3(1, ny), dim3(64), 0, st, d);
+        if (any_short) hipLaunchKernelGGL(ck_wave_kernel, dim3(ny), dim3(64), 0, st, d);
         if (max_chunks == 0) continue;
         GODOT_REQUIRE((max_chunks + 8) * nt < ((int64_t)1 << 31), GODOT_E_UNSUPPORTED,
                       "godot_exposure_checkpoints: %lld tables of up to %lld rows in one call", (long long)nt,

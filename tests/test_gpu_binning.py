@@ -546,6 +546,14 @@ def _checkpoint_case(case, n, rng):
         x4 = (2 * rng.integers(0, 8, n) + 1) * 2.0 ** -30
         x4[0] = 2.0 ** 23
         return x1, x4
+    if case == 'negzero':
+        # sums that begin with -0.0 keep its sign until the first +0.0 or nonzero row
+        x1 = np.where(rng.random(n) < 0.5, -0.0, 0.0)
+        x1[:3] = -0.0
+        x1[n // 2:] = np.where(rng.random(n - n // 2) < 0.3, 1.5, -0.0)
+        x4 = np.full(n, -0.0)
+        x4[n - 1] = 0.0
+        return x1, x4
     if case == 'zeros':
         x1 = np.where(rng.random(n) < 0.7, 0.0, rng.uniform(0, 1e5, n))
         x1[:min(5000, n // 2)] = 0.0
@@ -564,7 +572,8 @@ def test_checkpoints_of_many_tables_are_numpy_cumsum_at_every_sixteenth_row():
     tables, want = [], []
     for k, (case, n) in enumerate((('realistic', 150_001), ('ties', 150_000), ('zeros', 40_960), ('range', 8_192),
                                    ('realistic', 8_191), ('range', 17), ('ties', 16), ('zeros', 1),
-                                   ('ties', 263_000))):
+                                   ('ties', 263_000), ('negzero', 40), ('negzero', 700), ('range', 512),
+                                   ('ties', 513), ('realistic', 1_025), ('zeros', 4_097))):
         x1, x4 = _checkpoint_case(case, n, rng)
         se, be = 0.173 + 0.01 * k, 0.827 - 0.01 * k
         z = torch.zeros(n, dtype=torch.float64, device=DEV)
@@ -582,6 +591,20 @@ def test_checkpoints_of_many_tables_are_numpy_cumsum_at_every_sixteenth_row():
         for c in range(4):
             assert _same_bits(np.ascontiguousarray(g[:, c]), np.ascontiguousarray(w[:, c])), \
                 (k, c, int(np.argmax(g[:, c] != w[:, c])))
+    # the full tables of the short ones hold the same sums (signs of zero included)
+    for k in (9, 10, 13):
+        t = tables[k]
+        n = t['tstart'].numel()
+        full = ops.exposure_table(t['tstart'], t['tstop'], t['exposure'], t['livetime'], t['s_over_e'], t['b_over_e'])
+        full = full[:32 * n].view(torch.float64).view(n, 4).cpu().numpy()
+        rows = np.minimum(np.arange(15, n + 15, 16), n - 1)
+        for c in range(4):
+            assert _same_bits(np.ascontiguousarray(full[rows, c]), np.ascontiguousarray(want[k][:, c])), (k, c)
+    # every table alone: a call of its own takes the same route as the table took among the others
+    for k in (0, 3, 4, 9, 11):
+        g = ops.exposure_checkpoints([tables[k]])[0]
+        nb = 32 * len(want[k])
+        assert torch.equal(g[:nb], got[k][:nb]), k
     assert ops.exposure_checkpoints([]) == []
 
 
