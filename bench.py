@@ -387,186 +387,205 @@ def run_rank(args):
         torch.cuda.empty_cache()
 
     # ---- strong scaling, collectives inside the timed region -----------------------
+    # Every leg stands alone: one that fails (on every rank alike: the ranks run the same code on the
+    # same sizes) leaves its error in `extra` and the others, and the headline above, are still reported.
     if not args.no_extra:
-        # (1) the cells of ONE photon list (seed 11 on every rank) split by photon count; every
-        # step fits the rank's shard and all-gathers the (alpha, TS) records of all cells
-        if rank == 0:
-            cr_all = crs[0]
-        else:
-            s0 = synth.synth(args.nph, years=args.years, seed=11)
-            d0 = core.Data(s0['ti'], s0['we'], s0['TSTART'], s0['TSTOP'], s0['LIVETIME'], s0['exposure'], device=dev)
-            cr_all = d0.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True).ranges()
-            del s0, d0
-        counts = (cr_all.hi - cr_all.lo).cpu().numpy()
-        c0, c1 = gd.cell_shard(counts, rank, world)
-        mine = cr_all.shard(c0, c1, photons=int(counts[c0:c1].sum()))
-        sizes = [gd.cell_shard(counts, r, world)[1] - gd.cell_shard(counts, r, world)[0] for r in range(world)]
+        def leg_c2():
+            # (1) the cells of ONE photon list (seed 11 on every rank) split by photon count; every
+            # step fits the rank's shard and all-gathers the (alpha, TS) records of all cells
+            if rank == 0:
+                cr_all = crs[0]
+            else:
+                s0 = synth.synth(args.nph, years=args.years, seed=11)
+                d0 = core.Data(s0['ti'], s0['we'], s0['TSTART'], s0['TSTOP'], s0['LIVETIME'], s0['exposure'], device=dev)
+                cr_all = d0.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True).ranges()
+                del s0, d0
+            counts = (cr_all.hi - cr_all.lo).cpu().numpy()
+            c0, c1 = gd.cell_shard(counts, rank, world)
+            mine = cr_all.shard(c0, c1, photons=int(counts[c0:c1].sum()))
+            sizes = [gd.cell_shard(counts, r, world)[1] - gd.cell_shard(counts, r, world)[0] for r in range(world)]
 
-        def strong_step():
-            a, t, _ = ops.cell_fit(mine)
-            rec = torch.stack([a, t], dim=1)
-            return gd.all_gather_ragged(rec.to(cdev), sizes=sizes)
+            def strong_step():
+                a, t, _ = ops.cell_fit(mine)
+                rec = torch.stack([a, t], dim=1)
+                return gd.all_gather_ragged(rec.to(cdev), sizes=sizes)
 
-        for _ in range(5):
-            rec = strong_step()
-        nstrong = max(10, args.steps // 4)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nstrong):
-            rec = strong_step()
-        torch.cuda.synchronize()
-        barrier()
-        t_strong = max_over_ranks(time.perf_counter() - t0) / nstrong
-        extra['strong_c2_fit'] = dict(cells_per_s=len(counts) / t_strong, ms_per_step=t_strong * 1e3,
-                                      ncell=int(len(counts)), n_gpus=world, records_gathered=int(rec.shape[0]),
-                                      cells_on_rank0=int(c1 - c0),
-                                      sharding='cells split by photon count (dist.cell_shard), (alpha, TS) '
-                                               'records all-gathered inside every timed step')
-        del rec, mine
-        # (2) C4: 1e6 photons x nfreq trial frequencies, m = 2, frequencies split over the ranks,
-        # global top ten gathered; the search runs in launches of 2^21 frequencies
-        zs = synth.synth(1_000_000, years=1.0, seed=17)
-        zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
-        zw = torch.from_numpy(zs['we']).to(dev)
-        zspan = float(zs['ti'][-1] - zs['ti'][0])
-        zf0, zdf = 1e-4, 1.0 / (4 * zspan)
-        chunk = 1 << 21
-        kernel_ms = []
-        j0_mine, n_mine = gd.frequency_shard(args.nfreq, rank, world)
-        # the workspace of a launch is not monotonic in its number of frequencies (fewer frequencies are
-        # split over more groups of photons): sized for the full launches and for the last, shorter one
-        zneed = max(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), nn_, 2)
-                    for nn_ in {chunk, n_mine % chunk or chunk, min(chunk, max(n_mine, 1))})
-        zws = torch.empty(zneed, dtype=torch.uint8, device=dev)
-        zbuf = torch.empty(n_mine, dtype=torch.float64, device=dev)
+            for _ in range(5):
+                rec = strong_step()
+            nstrong = max(10, args.steps // 4)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nstrong):
+                rec = strong_step()
+            torch.cuda.synchronize()
+            barrier()
+            t_strong = max_over_ranks(time.perf_counter() - t0) / nstrong
+            extra['strong_c2_fit'] = dict(cells_per_s=len(counts) / t_strong, ms_per_step=t_strong * 1e3,
+                                          ncell=int(len(counts)), n_gpus=world, records_gathered=int(rec.shape[0]),
+                                          cells_on_rank0=int(c1 - c0),
+                                          sharding='cells split by photon count (dist.cell_shard), (alpha, TS) '
+                                                   'records all-gathered inside every timed step')
+            del rec, mine
 
-        def search_fn(j0, n):
-            """The statistic on this rank's slice, launch by launch, into one buffer."""
-            for k0 in range(0, n, chunk):
-                nn = min(chunk, n - k0)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                zbuf[k0:k0 + nn] = ops.z2m(zt, zw, zf0, zdf, nn, m=2, j0=j0 + k0, workspace=zws)[0]
-                e1.record(stream)
-                kernel_ms.append((e0, e1, nn))
-            return zbuf[:n]
+        def leg_c4():
+            # (2) C4: 1e6 photons x nfreq trial frequencies, m = 2, frequencies split over the ranks,
+            # global top ten gathered; the search runs in launches of 2^21 frequencies
+            zs = synth.synth(1_000_000, years=1.0, seed=17)
+            zt = torch.from_numpy(zs['ti'] - zs['ti'][0]).to(dev)
+            zw = torch.from_numpy(zs['we']).to(dev)
+            zspan = float(zs['ti'][-1] - zs['ti'][0])
+            zf0, zdf = 1e-4, 1.0 / (4 * zspan)
+            chunk = 1 << 21
+            kernel_ms = []
+            j0_mine, n_mine = gd.frequency_shard(args.nfreq, rank, world)
+            # the workspace of a launch is not monotonic in its number of frequencies (fewer frequencies are
+            # split over more groups of photons): sized for the full launches and for the last, shorter one
+            zneed = max(ops._lib.lib.godot_z2m_workspace_bytes(zt.numel(), nn_, 2)
+                        for nn_ in {chunk, n_mine % chunk or chunk, min(chunk, max(n_mine, 1))})
+            zws = torch.empty(zneed, dtype=torch.uint8, device=dev)
+            zbuf = torch.empty(n_mine, dtype=torch.float64, device=dev)
 
-        def topk_sharded():
-            return gd.search_topk_sharded(args.nfreq, search_fn, k=10)
+            def search_fn(j0, n):
+                """The statistic on this rank's slice, launch by launch, into one buffer."""
+                for k0 in range(0, n, chunk):
+                    nn = min(chunk, n - k0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    zbuf[k0:k0 + nn] = ops.z2m(zt, zw, zf0, zdf, nn, m=2, j0=j0 + k0, workspace=zws)[0]
+                    e1.record(stream)
+                    kernel_ms.append((e0, e1, nn))
+                return zbuf[:n]
 
-        ops.z2m(zt, zw, zf0, zdf, chunk, m=2, workspace=zws)        # warm-up launch
-        torch.cuda.synchronize()
-        kernel_ms.clear()
-        barrier()
-        t0 = time.perf_counter()
-        top_v, top_i = topk_sharded()
-        torch.cuda.synchronize()
-        barrier()
-        z_s = max_over_ranks(time.perf_counter() - t0)
-        k_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_ms)
-        k_n = sum(nn for _, _, nn in kernel_ms)
-        evals = float(zt.numel()) * args.nfreq / z_s
-        zrec = dict(photon_freq_evals_per_s=evals, s=z_s, nph=zt.numel(), nfreq=args.nfreq, m=2, n_gpus=world,
-                    z2_max=float(top_v[0]), argmax=int(top_i[0]),
-                    top_ten_indices=[int(i) for i in top_i], top_ten_values=[float(v) for v in top_v],
-                    kernel_evals_per_s_rank0=float(zt.numel()) * k_n / (k_ms * 1e-3),
-                    sharding='frequencies split (dist.frequency_shard), photons replicated, per-rank top ten '
-                             'all-gathered')
-        if os.path.exists(Z2M_FLOP_FILE):
-            with open(Z2M_FLOP_FILE) as f:
-                zf = json.load(f)
-            fpe = zf.get('fp64_flop_per_evaluation')
-            if fpe:
-                zrec['hardware_counted_fp64_flop_per_eval'] = fpe
-                zrec['executed_frac_of_fp64_peak'] = fpe * evals / (FP64_PEAK_TFLOPS * 1e12 * world)
-        extra['strong_c4_z2m'] = zrec
-        del zws, zt, zw, zbuf
-        torch.cuda.empty_cache()
-        # (3) C3: ONE power spectrum (3 786 912 bins of 100 s, l = 2^25) with its five transforms
-        # dealt over the ranks; every step transforms the rank's series, all-gathers the five
-        # transforms cut to what the estimators read and forms the estimators on every rank.
-        # (On one GPU the whole call is a single fused pipeline: extra.power_spectrum_fft.)
-        nb3, l3 = 3_786_912, 1 << 25
-        gen3 = torch.Generator(device=dev)
-        gen3.manual_seed(13)                                   # the same series on every rank
-        cnt3 = torch.poisson(torch.full((nb3,), 2.6, dtype=torch.float64, device=dev), generator=gen3)
-        W3, WW3 = cnt3 * 0.17, cnt3 * 0.08
-        S3 = torch.full((nb3,), 0.44, dtype=torch.float64, device=dev)
-        B3 = S3 * 5
-        Wb3, WbWb3 = cnt3 - W3, cnt3 - 2 * W3 + WW3
-        series3 = [W3 - S3, Wb3 - B3, WW3, WbWb3, W3 - WW3]
+            def topk_sharded():
+                return gd.search_topk_sharded(args.nfreq, search_fn, k=10)
 
-        # the four-step form where the ranks divide the columns (a power of two of them): every rank
-        # transforms its columns, an all-to-all (point to point) gives every rank whole rows, the
-        # estimators of a rank's rows are summed over the ranks; else whole transforms are dealt out
-        four_step = world > 1 and ops.power_spectrum_parts_supported(nb3, l3, world)
-        c3_method = ('four-step: columns split, all-to-all of 28 l bytes, rows split; every rank keeps the bins of its '
-                     'rows (the largest P_1 is all-reduced)'
-                     if four_step else ('one fused call' if world == 1 else
-                                        'whole transforms dealt over the ranks (dist.transform_shard), cut transforms '
-                                        'all-gathered, estimators on every rank'))
+            ops.z2m(zt, zw, zf0, zdf, chunk, m=2, workspace=zws)        # warm-up launch
+            torch.cuda.synchronize()
+            kernel_ms.clear()
+            barrier()
+            t0 = time.perf_counter()
+            top_v, top_i = topk_sharded()
+            torch.cuda.synchronize()
+            barrier()
+            z_s = max_over_ranks(time.perf_counter() - t0)
+            k_ms = sum(a.elapsed_time(b) for a, b, _ in kernel_ms)
+            k_n = sum(nn for _, _, nn in kernel_ms)
+            evals = float(zt.numel()) * args.nfreq / z_s
+            zrec = dict(photon_freq_evals_per_s=evals, s=z_s, nph=zt.numel(), nfreq=args.nfreq, m=2, n_gpus=world,
+                        z2_max=float(top_v[0]), argmax=int(top_i[0]),
+                        top_ten_indices=[int(i) for i in top_i], top_ten_values=[float(v) for v in top_v],
+                        kernel_evals_per_s_rank0=float(zt.numel()) * k_n / (k_ms * 1e-3),
+                        sharding='frequencies split (dist.frequency_shard), photons replicated, per-rank top ten '
+                                 'all-gathered')
+            if os.path.exists(Z2M_FLOP_FILE):
+                with open(Z2M_FLOP_FILE) as f:
+                    zf = json.load(f)
+                fpe = zf.get('fp64_flop_per_evaluation')
+                if fpe:
+                    zrec['hardware_counted_fp64_flop_per_eval'] = fpe
+                    zrec['executed_frac_of_fp64_peak'] = fpe * evals / (FP64_PEAK_TFLOPS * 1e12 * world)
+            extra['strong_c4_z2m'] = zrec
+            del zws, zt, zw, zbuf
+            torch.cuda.empty_cache()
 
-        def c3_step():
-            if four_step:
-                return gd.power_spectrum_fft_four_step(
-                    W3, WW3, S3, Wb3, WbWb3, B3, l3,
-                    lambda part, nparts: ops.power_spectrum_columns(W3, WW3, S3, Wb3, WbWb3, B3, l3, part, nparts),
-                    lambda v, dc, m0, m1: ops.power_spectrum_rows(v, dc, l3, m0, m1)[:3],
-                    lambda nrows: ops.power_spectrum_part_shapes(l3, 1, nrows), gather=False)
-            if world == 1:
-                return ops.power_spectrum_fft(W3, WW3, S3, Wb3, WbWb3, B3, l3)[:3]
-            return gd.power_spectrum_fft_sharded(lambda i: series3[i], l3, ops.rfft,
-                                                 lambda *parts: ops.power_spectrum_from_parts(*parts))
+        def leg_c3():
+            # (3) C3: ONE power spectrum (3 786 912 bins of 100 s, l = 2^25) with its five transforms
+            # dealt over the ranks; every step transforms the rank's series, all-gathers the five
+            # transforms cut to what the estimators read and forms the estimators on every rank.
+            # (On one GPU the whole call is a single fused pipeline: extra.power_spectrum_fft.)
+            nb3, l3 = 3_786_912, 1 << 25
+            gen3 = torch.Generator(device=dev)
+            gen3.manual_seed(13)                                   # the same series on every rank
+            cnt3 = torch.poisson(torch.full((nb3,), 2.6, dtype=torch.float64, device=dev), generator=gen3)
+            W3, WW3 = cnt3 * 0.17, cnt3 * 0.08
+            S3 = torch.full((nb3,), 0.44, dtype=torch.float64, device=dev)
+            B3 = S3 * 5
+            Wb3, WbWb3 = cnt3 - W3, cnt3 - 2 * W3 + WW3
+            series3 = [W3 - S3, Wb3 - B3, WW3, WbWb3, W3 - WW3]
 
-        for _ in range(2):
-            c3_step()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            p3 = c3_step()
-        torch.cuda.synchronize()
-        barrier()
-        t_c3 = max_over_ranks(time.perf_counter() - t0) / 5
-        p1_max3 = max_over_ranks(float(torch.nan_to_num(p3[1][1:], nan=-np.inf).max().cpu()))
-        extra['strong_c3_fft'] = dict(ms=t_c3 * 1e3, nbins=nb3, l=l3, n_gpus=world,
-                                      exchanged_MB=(16.0 * (l3 + 3 * l3 // 4) * (world - 1) / world / 1e6
-                                                    if four_step else (5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0)),
-                                      p0_at_bin_1=float(p3[0][1]), p1_at_bin_1000=float(p3[1][1000]), p1_max=p1_max3,
-                                      sharding=c3_method)
-        del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
-        torch.cuda.empty_cache()
-        # (4) C5: 256 sources x 1e6 photons dealt round-robin over the ranks; every rank runs its
-        # sources as one job (core.run_sources, tables built inside) and the per-source summaries
-        # are all-gathered.  The sources are made before the clock starts.
-        nsrc5 = 256
-        mine5 = gd.source_shard(nsrc5, rank, world)
-        made5 = [core.Data(s_['ti'], s_['we'], s_['TSTART'], s_['TSTOP'], s_['LIVETIME'], s_['exposure'], device=dev)
-                 for s_ in synth.synth_sources_device(nsrc5, dev, years=args.years, indices=mine5)]
-        core.pack_sources(made5)
+            # the four-step form where the ranks divide the columns (a power of two of them): every rank
+            # transforms its columns, an all-to-all (point to point) gives every rank whole rows, the
+            # estimators of a rank's rows are summed over the ranks; else whole transforms are dealt out
+            four_step = world > 1 and ops.power_spectrum_parts_supported(nb3, l3, world)
+            c3_method = ('four-step: columns split, all-to-all of 28 l bytes, rows split; every rank keeps the bins of its '
+                         'rows (the largest P_1 is all-reduced)'
+                         if four_step else ('one fused call' if world == 1 else
+                                            'whole transforms dealt over the ranks (dist.transform_shard), cut transforms '
+                                            'all-gathered, estimators on every rank'))
 
-        def c5_step():
-            for d_ in made5:
-                d_._checkpoints = None
-            return gd.run_sources_sharded(nsrc5, lambda idx: made5, 86400., 300.)
+            def c3_step():
+                if four_step:
+                    return gd.power_spectrum_fft_four_step(
+                        W3, WW3, S3, Wb3, WbWb3, B3, l3,
+                        lambda part, nparts: ops.power_spectrum_columns(W3, WW3, S3, Wb3, WbWb3, B3, l3, part, nparts),
+                        lambda v, dc, m0, m1: ops.power_spectrum_rows(v, dc, l3, m0, m1)[:3],
+                        lambda nrows: ops.power_spectrum_part_shapes(l3, 1, nrows), gather=False)
+                if world == 1:
+                    return ops.power_spectrum_fft(W3, WW3, S3, Wb3, WbWb3, B3, l3)[:3]
+                return gd.power_spectrum_fft_sharded(lambda i: series3[i], l3, ops.rfft,
+                                                     lambda *parts: ops.power_spectrum_from_parts(*parts))
 
-        c5_step()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        summ5, _ = c5_step()
-        torch.cuda.synchronize()
-        barrier()
-        t_c5 = max_over_ranks(time.perf_counter() - t0)
-        extra['strong_c5_sources'] = dict(sources=nsrc5, sources_on_rank0=len(mine5), n_gpus=world, s=t_c5,
-                                          sources_per_s=nsrc5 / t_c5,
-                                          largest_p1_first_four=[float(x) for x in summ5[:4, 1]],
-                                          sharding='sources dealt round-robin (dist.source_shard), every rank runs its '
-                                                   'own as one job, 64-byte summaries all-gathered')
-        del made5
-        torch.cuda.empty_cache()
+            for _ in range(2):
+                c3_step()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                p3 = c3_step()
+            torch.cuda.synchronize()
+            barrier()
+            t_c3 = max_over_ranks(time.perf_counter() - t0) / 5
+            p1_max3 = max_over_ranks(float(torch.nan_to_num(p3[1][1:], nan=-np.inf).max().cpu()))
+            extra['strong_c3_fft'] = dict(ms=t_c3 * 1e3, nbins=nb3, l=l3, n_gpus=world,
+                                          exchanged_MB=(16.0 * (l3 + 3 * l3 // 4) * (world - 1) / world / 1e6
+                                                        if four_step else (5 * 16 * (l3 // 4 + 1) / 1e6 if world > 1 else 0.0)),
+                                          p0_at_bin_1=float(p3[0][1]), p1_at_bin_1000=float(p3[1][1000]), p1_max=p1_max3,
+                                          sharding=c3_method)
+            del cnt3, W3, WW3, S3, B3, Wb3, WbWb3, series3, p3
+            torch.cuda.empty_cache()
+
+        def leg_c5():
+            # (4) C5: 256 sources x 1e6 photons dealt round-robin over the ranks; every rank runs its
+            # sources as one job (core.run_sources, tables built inside) and the per-source summaries
+            # are all-gathered.  The sources are made before the clock starts.
+            nsrc5 = 256
+            mine5 = gd.source_shard(nsrc5, rank, world)
+            made5 = [core.Data(s_['ti'], s_['we'], s_['TSTART'], s_['TSTOP'], s_['LIVETIME'], s_['exposure'], device=dev)
+                     for s_ in synth.synth_sources_device(nsrc5, dev, years=args.years, indices=mine5)]
+            core.pack_sources(made5)
+
+            def c5_step():
+                for d_ in made5:
+                    d_._checkpoints = None
+                return gd.run_sources_sharded(nsrc5, lambda idx: made5, 86400., 300.)
+
+            c5_step()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            summ5, _ = c5_step()
+            torch.cuda.synchronize()
+            barrier()
+            t_c5 = max_over_ranks(time.perf_counter() - t0)
+            extra['strong_c5_sources'] = dict(sources=nsrc5, sources_on_rank0=len(mine5), n_gpus=world, s=t_c5,
+                                              sources_per_s=nsrc5 / t_c5,
+                                              largest_p1_first_four=[float(x) for x in summ5[:4, 1]],
+                                              sharding='sources dealt round-robin (dist.source_shard), every rank runs its '
+                                                       'own as one job, 64-byte summaries all-gathered')
+            del made5
+            torch.cuda.empty_cache()
+
+        for name_, leg_ in (('strong_c2_fit', leg_c2), ('strong_c4_z2m', leg_c4), ('strong_c3_fft', leg_c3),
+                            ('strong_c5_sources', leg_c5)):
+            try:
+                leg_()
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                extra[name_] = dict(error='%s: %s' % (type(e).__name__, e), n_gpus=world)
+            torch.cuda.empty_cache()
 
     if rank != 0:
         if dist is not None:
