@@ -1,7 +1,7 @@
 // Fit kernel for sparse cells (a few to a few tens of photons per cell): the
 // shape the ten-minute light curves of the reference produce.
 //
-// A group of L adjacent lanes (L = 1, 2 or 4) owns one cell and keeps its
+// A group of L adjacent lanes (L = 1 ... 64) owns one cell and keeps its
 // weights in R registers per lane for the whole fixed schedule of
 // CellLogLikelihood.get_max (reference core.py:632-691) and for get_ts
 // (core.py:982-994), so a wavefront fits 64/L cells at once and the per-cell
@@ -14,8 +14,9 @@
 // loads into LDS; lanes then pick their weights out of it with unconditional
 // reads at fixed offsets.  No barrier anywhere: wavefronts on a CU drift apart
 // and the loads of one overlap the arithmetic of the others.  Photons beyond
-// the L*R register slots of a cell (rare by the choice of L and R) are read
-// from the LDS copy in every pass.
+// the L*R register slots of a cell are read from the LDS copy in every pass,
+// in rounds of four more slots a lane that the whole wavefront makes (as many
+// as its largest cell needs), with the reciprocals of a round from one rcp.
 //
 // Cells whose first pass of the schedule asks for a restart (1 to 10 in 100,
 // more the sparser the cells) are handed to a second kernel through the sign
@@ -40,11 +41,28 @@ struct GroupCell {
     int n;              // photons in the cell
     int q;              // lane inside the group
     bool tail_swap;     // tp points to raw weights that are to be complemented
+    int tg;             // photons beyond the register slots: rounds of four more slots a lane that the
+                        // wavefront's largest cell needs (the same in every lane: a scalar loop count)
 
     __device__ __forceinline__ double tail(int j) const
     {
         double v = tp[j];
         return tail_swap ? 1.0 - v : v;
+    }
+
+    // photon j of the cell, or the zero of an empty slot
+    __device__ __forceinline__ double tail0(int j) const
+    {
+        double v = 0.0;
+        if (j < n) v = tail(j);
+        return v;
+    }
+
+    // rounds of the wavefront for cells of at most nmax photons
+    static __device__ __forceinline__ int tail_rounds(int nmax)
+    {
+        const int over = __builtin_amdgcn_readfirstlane(team_max_i32<64>(nmax)) - SLOTS;
+        return over > 0 ? (over + 4 * L - 1) / (4 * L) : 0;
     }
 
     template <int NS, bool ZS = false, class F>
@@ -55,7 +73,13 @@ struct GroupCell {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (ZS || r * L + q < n) f(w[r], acc);
-        for (int j = SLOTS + q; j < n; j += L) f(tail(j), acc);
+        for (int g = 0; g < tg; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = SLOTS + (4 * g + k) * L + q;
+                if (j < n) f(tail(j), acc);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
     }
@@ -78,9 +102,16 @@ struct GroupCell {
             accf(w[r + 2], d2, x2, acc);
             accf(w[r + 3], d3, x3, acc);
         }
-        for (int j = SLOTS + q; j < n; j += L) {
-            const double wv = tail(j), d = den(wv);
-            accf(wv, d, rcp_fast1(d), acc);
+        for (int g = 0; g < tg; ++g) {
+            const int j = SLOTS + 4 * g * L + q;
+            const double w0 = tail0(j), w1 = tail0(j + L), w2 = tail0(j + 2 * L), w3 = tail0(j + 3 * L);
+            const double d0 = den(w0), d1 = den(w1), d2 = den(w2), d3 = den(w3);
+            double x0, x1, x2, x3;
+            rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+            accf(w0, d0, x0, acc);
+            accf(w1, d1, x1, acc);
+            accf(w2, d2, x2, acc);
+            accf(w3, d3, x3, acc);
         }
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] = team_sum<L>(acc[k]);
@@ -109,12 +140,18 @@ struct GroupCell {
             pr *= (d0 * d1) * (d2 * d3);
             if ((r & 4) != 0) renorm();
         }
-        int k = 0;
-        for (int j = SLOTS + q; j < n; j += L) {
-            const double wv = tail(j), d = den(wv);
-            gs += gf(wv, rcp_fast1(d));
-            pr *= d;
-            if ((++k & 7) == 0) renorm();
+        for (int g = 0; g < tg; ++g) {
+            const int j = SLOTS + 4 * g * L + q;
+            const double w0 = tail0(j), w1 = tail0(j + L), w2 = tail0(j + 2 * L), w3 = tail0(j + 3 * L);
+            const double d0 = den(w0), d1 = den(w1), d2 = den(w2), d3 = den(w3);
+            double x0, x1, x2, x3;
+            rcp4(d0, d1, d2, d3, x0, x1, x2, x3);
+            gs += gf(w0, x0);
+            gs += gf(w1, x1);
+            gs += gf(w2, x2);
+            gs += gf(w3, x3);
+            pr *= (d0 * d1) * (d2 * d3);
+            if ((g & 1) != 0) renorm();
         }
         renorm();
         reduce_prod(pr, ex);
@@ -129,7 +166,13 @@ struct GroupCell {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (r * L + q < n) m = fmax(m, w[r]);
-        for (int j = SLOTS + q; j < n; j += L) m = fmax(m, tail(j));
+        for (int g = 0; g < tg; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = SLOTS + (4 * g + k) * L + q;
+                if (j < n) m = fmax(m, tail(j));
+            }
+        }
         return team_max<L>(m);
     }
 
@@ -148,8 +191,15 @@ struct GroupCell {
         };
 #pragma unroll
         for (int r = 0; r < R; ++r) step(w[r], r);
-        int k = R;
-        for (int j = SLOTS + q; j < n; j += L) step(tail(j), k++);
+        for (int g = 0; g < tg; ++g) {
+            // an empty slot multiplies by f(0): 1 for every product taken here
+            const int j = SLOTS + 4 * g * L + q;
+            pr *= (f(tail0(j)) * f(tail0(j + L))) * (f(tail0(j + 2 * L)) * f(tail0(j + 3 * L)));
+            if ((g & 1) != 0) {
+                ex += __builtin_amdgcn_frexp_exp(pr);
+                pr = __builtin_amdgcn_frexp_mant(pr);
+            }
+        }
         ex += __builtin_amdgcn_frexp_exp(pr);
         pr = __builtin_amdgcn_frexp_mant(pr);
         reduce_prod(pr, ex);
@@ -190,8 +240,13 @@ struct GroupCell {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (ZS || r * L + q < n) step(w[r], r);
-        int k = R;
-        for (int j = SLOTS + q; j < n; j += L) step(tail(j), k++);
+        for (int g = 0; g < tg; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = SLOTS + (4 * g + k) * L + q;
+                if (j < n) step(tail(j), 4 * g + k + 3);   // renormalised after the fourth of a round
+            }
+        }
         renorm();
         p1 = team_prod<L>(p1);   // at most four factors in [0.5, 1)
         p2 = team_prod<L>(p2);
@@ -230,6 +285,7 @@ __device__ __forceinline__ void gather_cell(GroupCell<L, R> &gc, const double *g
     gc.n = n;
     gc.q = q;
     gc.tail_swap = swap;
+    gc.tg = GroupCell<L, R>::tail_rounds(n);
 #pragma unroll
     for (int r = 0; r < R; ++r) gc.w[r] = 0.0;
     if (n > 0) {
@@ -311,7 +367,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
     // mean may come to within two sigma of the 4 R slots, so that the run needs more room.
     // (the largest shape also takes cells half again as long as its 2 048 slots: what does not
     // fit the registers is read from the slice in every pass)
-    constexpr int BOUNCE = (L == 64 && R == 32 ? 96 : L >= 4 ? 64 : 52) * R;
+    constexpr int BOUNCE = (L == 1 && R >= 24) ? 128 * ((42 * R + 64) / 128) : (L == 64 && R == 32 ? 96 : L >= 4 ? 64 : 52) * R;
     constexpr int NLOAD = (BOUNCE + 63) / 64;
     constexpr int NWIDE = (BOUNCE + 127) / 128;   // rows of 128 photons: 16 bytes a lane
     using GC = GroupCell<L, R>;
@@ -409,6 +465,7 @@ __device__ __forceinline__ void cell_fit_group_body(const CellArgs &p, const dou
         gc.n = n;
         gc.q = q;
         gc.tail_swap = false;
+        gc.tg = GC::tail_rounds(n);
     } else {
         gather_cell(gc, p.we + (bad ? 0 : lo), n, q, swap);
     }
@@ -665,9 +722,10 @@ __device__ __forceinline__ void cell_fit_restart_body(const CellArgs &p, const d
 
 // register budget: five wavefronts per SIMD (twenty LDS slices per CU); the
 // variant that repeats restarts in place needs the registers of four per SIMD
-// to stay clear of scratch memory (measured: faster so)
+// to stay clear of scratch memory (measured: faster so); 32 slots a lane and
+// more need those of three (their LDS slices allow ten to twelve a CU anyway)
 template <int L, int R, bool INPLACE>
-__global__ __launch_bounds__(64, INPLACE ? 4 : 5) void cell_fit_group_b0_kernel(CellArgs p, const double *guess,
+__global__ __launch_bounds__(64, (R >= 32 && !(L == 64 && R == 32)) ? 3 : INPLACE ? 4 : 5) void cell_fit_group_b0_kernel(CellArgs p, const double *guess,
                                                                   double guess0, const double *beta,
                                                                   double beta0, double *alpha, double *ts,
                                                                   int32_t *flags)
@@ -676,7 +734,7 @@ __global__ __launch_bounds__(64, INPLACE ? 4 : 5) void cell_fit_group_b0_kernel(
 }
 
 template <int L, int R, bool INPLACE>
-__global__ __launch_bounds__(64, INPLACE ? 4 : 5) void cell_fit_group_bx_kernel(CellArgs p, const double *guess,
+__global__ __launch_bounds__(64, (R >= 32 && !(L == 64 && R == 32)) ? 3 : INPLACE ? 4 : 5) void cell_fit_group_bx_kernel(CellArgs p, const double *guess,
                                                                   double guess0, const double *beta,
                                                                   double beta0, double *alpha, double *ts,
                                                                   int32_t *flags)
@@ -914,13 +972,24 @@ __global__ __launch_bounds__(64, 3) void cell_logpdf_group_kernel(CellArgs p, co
 namespace godot_detail {
 
 // Shape of the lane groups (L lanes a cell, R register slots a lane) for a mean
-// occupancy.  The one-lane shapes and the first two-lane shape hold the mean plus two
-// (Poisson) sigma in their L*R slots.  From there on the cells of a light curve are what
-// decides: their sizes spread wider than Poisson (the exposure of a cell varies along the
-// orbit; ten-minute cells of 22.6 photons on average have a standard deviation of 7, not
-// 4.8), and every photon beyond the slots costs a trip through the tail loops in all five
-// passes, so the two-lane shapes are chosen to hold the mean plus three sigma (ten-minute cells of 1e7 photons in ten years: 2 x 20
-// slots, 41.7 us against 49.3 us with 2 x 16).  Larger cells take 4 to 64 lanes: measured
+// occupancy.  A wavefront spends about 700 vector instructions on what does not depend on
+// the number of slots (ranges, staging, the steps of the schedule, the logarithm, results,
+// restarts) and about 29 on every slot of a lane, whatever L is: the fewer lanes a cell
+// takes, the more cells share those 700.  The fit (grid = false) therefore gives cells of up
+// to 23 photons on average ONE lane of 24, 32 or 40 slots (the mean plus 3.5 sqrt(mean):
+// the cells of a light curve spread wider than Poisson because the exposure of a cell varies
+// along the orbit -- ten-minute cells of 22.6 photons on average have a standard deviation
+// of 7, not 4.8); what a cell holds beyond its slots is taken in rounds of four more slots
+// that the whole wavefront makes (GroupCell::tg).  Measured on 10^7 photons, 1 x 40 against
+// 2 x 20 at 22.6 photons a cell: 1.47e7 against 1.78e7 vector instructions a launch; single
+// launches 43-46 us both (ten to eleven wavefronts of twice the length a compute unit: the
+// launch ends on a longer tail), four lists in one launch 36 against 39 us a list, launches
+// overlapping on three streams 33 against 36 us; 1 x 32 against 2 x 12 / 2 x 16 at 12, 15
+// and 17 photons a cell: 61, 55, 45 us against 69, 60, 49 us; 2 x 32 against 4 x 12 at 36
+// photons a cell: 39-42 against 44-49 us.  The profile grid keeps the two-lane shapes: its
+// lanes fetch their cells straight from memory, 64 runs a wavefront instead of 32, and it
+// measured 0.81 against 0.68 ms with one lane a cell.  Two lanes hold the mean plus three
+// sigma, larger cells take 4 to 64 lanes: measured
 // on 10^7 photons these shapes fit cells of 40 to 1 400 photons in 35-45 us and form their
 // profile grids in 0.32-0.52 ms, where the team-per-cell kernels of cells.hip take 40-66 us
 // and 0.48-0.72 ms.  The largest shape keeps 3 072 photons in its LDS slice and reads what
@@ -932,11 +1001,17 @@ bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid)
 {
     const double mean = ncell > 0 ? (double)godot_shape_photons(nph) / (double)ncell : 0.0;
     const double need = mean + 2.0 * sqrt(mean), wide = mean + 3.0 * sqrt(mean);
+    const double one = mean + 3.5 * sqrt(mean);
+    const bool fit = !grid;
     if (need <= 9.0) { L = 1; R = 8; }
     else if (need <= 17.0) { L = 1; R = 16; }
+    else if (one <= 24.0 && fit) { L = 1; R = 24; }
+    else if (one <= 32.0 && fit) { L = 1; R = 32; }
+    else if (one <= 40.0 && fit) { L = 1; R = 40; }
     else if (need <= 25.0) { L = 2; R = 12; }
     else if (wide <= 33.0) { L = 2; R = 16; }
-    else if (wide <= 41.0) { L = 2; R = 20; }
+    else if (wide <= (fit ? 44.0 : 41.0)) { L = 2; R = 20; }
+    else if (wide <= 60.0 && fit) { L = 2; R = 32; }
     else if (need <= 49.0) { L = 4; R = 12; }
     else if (need <= 66.0) { L = 4; R = 16; }
     else if (need <= 82.0) { L = 4; R = 20; }
@@ -997,11 +1072,13 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     }
     GK_LAUNCH_TWO(1, 8)
     GK_LAUNCH_TWO(1, 16)
-    GK_LAUNCH_TWO(2, 12)
-    GK_LAUNCH_INPLACE(2, 12)
-    GK_LAUNCH_INPLACE(2, 16)
     GK_LAUNCH_INPLACE(2, 20)
-    GK_LAUNCH_INPLACE(4, 12)
+    GK_LAUNCH_INPLACE(1, 24)
+    GK_LAUNCH_TWO(1, 24)
+    GK_LAUNCH_INPLACE(1, 32)
+    GK_LAUNCH_TWO(1, 32)
+    GK_LAUNCH_INPLACE(1, 40)
+    GK_LAUNCH_INPLACE(2, 32)
     GK_LAUNCH_INPLACE(4, 16)
     GK_LAUNCH_INPLACE(4, 20)
     GK_LAUNCH_INPLACE(4, 24)

@@ -112,6 +112,7 @@ GODOT_TEAM_REDUCE(team_sum_i32, int, dpp_i32, lane_i32, GODOT_OP_ADD)
 #define GODOT_OP_IMIN(a, b) (((b) < (a)) ? (b) : (a))
 GODOT_TEAM_REDUCE(team_fmax, double, dpp_f64, lane_f64, GODOT_OP_FMAX)    // ignores NaN
 GODOT_TEAM_REDUCE(team_min_i32, int, dpp_i32, lane_i32, GODOT_OP_IMIN)
+GODOT_TEAM_REDUCE(team_max_i32, int, dpp_i32, lane_i32, GODOT_OP_MAX)
 
 // 1/d for finite d away from 0 and from the ends of the exponent range:
 // hardware estimate + two Newton steps (about 1 ulp).  No scaling, no

@@ -207,6 +207,8 @@ def test_fit_matches_oracle_on_random_cells(nph, ncell):
 
 @pytest.mark.parametrize('mean,variant', [
     (4, 'plain'), (4, 'guess'), (9, 'plain'), (12.5, 'plain'), (12.5, 'beta'), (12.5, 'scattered'), (17, 'plain'),
+    # one lane of 24 slots, restarts by the second kernel; two lanes of 20 and of 32 slots
+    (11, 'plain'), (11, 'guess'), (11, 'swap'), (25, 'plain'), (25, 'beta'), (25, 'outliers'), (36, 'plain'), (36, 'swap'),
     (30, 'plain'), (30, 'beta'), (30, 'guess'),
     (22, 'plain'), (22, 'guess'), (22, 'beta'), (22, 'scattered'), (22, 'swap'), (40, 'plain'), (40, 'beta'),
     (22, 'outliers'),
