@@ -604,7 +604,7 @@ def run_rank(args):
     # HBM bytes per launch from the PMC passes (taken separately with rocprofv3 on this same
     # rotating workload and committed under profiles/; null when the workload differs)
     traffic = None
-    kernel_name = 'cell_fit_group_b0_kernel<2, 20, true>'
+    kernel_name = 'cell_fit_group_b0_kernel<1, 40, true>'
     if os.path.exists(FIT_TRAFFIC_FILE) and args.nph == 10_000_000 and args.tcell == 600.0 and args.years == 10.0:
         with open(FIT_TRAFFIC_FILE) as f:
             tj = json.load(f)
