@@ -896,10 +896,17 @@ class CellsLogLikelihood(object):
         tmid = 0.5 * (self.cells.starts + self.cells.stops)
         out_d = torch.empty((len(self.cells), 6), dtype=F64, device=rows.device)
         out_d[:, 1:] = rows
-        out_d[:, 0] = ops.met2mjd(tmid, MJDREF)
+        mjd = ops.met2mjd(tmid, MJDREF)
+        out_d[:, 0] = mjd
+        # Whether any time was left to the host is asked on the device: a pass of the host over
+        # a column of the page-locked result costs more than the copy itself (0.75 ms against
+        # 0.40 ms for 4.4e5 rows).  (The same call in four parts, the rows of a part on their way
+        # to the host while the quantiles of the next are taken, was measured: 1.05 ms against
+        # 0.89 ms, the launches and slices of the parts cost more than the overlap gains.)
+        left_any = torch.isnan(mjd).any()
         out = _np(out_d)
-        left = np.isnan(out[:, 0])
-        if left.any():
+        if bool(left_any):
+            left = np.isnan(out[:, 0])
             out[left, 0] = met2mjd(_np(tmid)[left])
         return out
 
