@@ -1962,8 +1962,9 @@ def power_spectrum_fft(timeseries, dfgoal=None, tweak_exp=False, exp_only=False,
         timeseries, dfgoal=dfgoal, tweak_exp=tweak_exp, exp_only=exp_only, get_amps=get_amps,
         exposure_correction=exposure_correction, no_zero_pad=no_zero_pad, maxN=maxN, device=device)
     # np.fft.rfftfreq(l) / tsamp cut to l // 4 + 1 bins (core.py:2679) without forming the other half of
-    # rfftfreq's array: the same products and quotients, element for element
-    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) / tsamp
+    # rfftfreq's array: the same products and quotients, element for element, formed on the device
+    # (the host takes 12 ms over the 8.4e6 bins of l = 2^25, fifteen times the transforms)
+    freqs = _np(ops.spectrum_frequencies(l // 4 + 1, 1.0 / l, tsamp, True, p0.device))
     if get_amps:
         a = _np(amps)
         return (freqs,) + tuple(a[i] for i in range(8))
@@ -1978,7 +1979,8 @@ def power_spectrum_simple(timeseries, get_amps=False, device=None):
     W, WW, S = _ts_dev(ts, 'weights', dev), _ts_dev(ts, 'weights2', dev), _ts_dev(ts, 'sexp', dev)
     l = W.numel()
     dl, mom = ops.power_spectrum_simple(W, WW, S, want_moments=get_amps)
-    freqs = (np.arange(l // 4 + 1) * (1.0 / l)) * (1. / ts.tsamp())   # rfftfreq(l)[:l // 4 + 1], same products
+    # rfftfreq(l)[:l // 4 + 1] * (1 / tsamp), same products
+    freqs = _np(ops.spectrum_frequencies(l // 4 + 1, 1.0 / l, 1. / ts.tsamp(), False, dl.device))
     if get_amps:
         m = _np(mom)
         return freqs, _np(dl), (m[0], m[1], m[2], m[3])

@@ -872,6 +872,31 @@ extern "C" int godot_power_spectrum_from_parts(const double *f1, const double *f
     return GODOT_OK;
 }
 
+namespace {
+// freqs[i] = (i * step) / scale or (i * step) * scale: one rounding per operation, as numpy makes them
+__global__ __launch_bounds__(256) void ps_frequencies_kernel(int64_t nk, double step, double scale, int divide,
+                                                             double *__restrict__ freqs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nk) return;
+    const double x = (double)i * step;
+    freqs[i] = divide ? x / scale : x * scale;
+}
+}   // namespace
+
+extern "C" int godot_spectrum_frequencies(int64_t nk, double step, double scale, int divide, double *freqs,
+                                          godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(nk >= 0, GODOT_E_INVALID, "godot_spectrum_frequencies: negative nk");
+    if (nk == 0) return GODOT_OK;
+    GODOT_REQUIRE(freqs, GODOT_E_INVALID, "godot_spectrum_frequencies: null pointer");
+    hipLaunchKernelGGL(ps_frequencies_kernel, dim3((unsigned)ceil_div(nk, (int64_t)256)), dim3(256), 0,
+                       (hipStream_t)stream, nk, step, scale, divide, freqs);
+    GODOT_LAUNCH_CHECK("godot_spectrum_frequencies");
+    return GODOT_OK;
+}
+
 extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, const double *S, int64_t n,
                                            double *dlogl, double *moments, void *workspace,
                                            size_t workspace_bytes, godot_stream_t stream)

@@ -188,6 +188,16 @@ def lightcurve_rows(tstart, tstop, alpha, ts, xlo, xhi, S, tsmin):
     return rows
 
 
+def spectrum_frequencies(nk, step, scale, divide, device):
+    """(i * step) / scale (divide) or (i * step) * scale for i < nk: the frequency axis of
+    power_spectrum_fft / power_spectrum_simple with numpy's roundings (core.py:2677-2679, 2765-2766)."""
+    out = torch.empty(int(nk), dtype=F64, device=device)
+    with torch.cuda.device(device):
+        _lib.call('godot_spectrum_frequencies', int(nk), float(step), float(scale), int(bool(divide)), _p(out),
+                  _stream(device))
+    return out
+
+
 def met2mjd(met, mjdref):
     """MJD of mission elapsed times with the reference's extended-precision roundings
     (core.py:24-26); NaN where the integer restatement does not apply."""

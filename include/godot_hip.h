@@ -519,6 +519,16 @@ int godot_power_spectrum_simple(const double *W, const double *WW,
                                 void *workspace, size_t workspace_bytes,
                                 godot_stream_t stream);
 
+/* The frequencies of the spectra above: np.fft.rfftfreq(l)[:nk] / tsamp
+ * (power_spectrum_fft, core.py:2677-2679: divide = 1) or * (1 / tsamp)
+ * (power_spectrum_simple, core.py:2765-2766: divide = 0, scale = 1 / tsamp),
+ * element for element numpy's roundings: freqs[i] = (i * step) / scale or
+ * (i * step) * scale with step = 1 / l.  Formed on the device because the host
+ * takes longer over these 8.4e6 products and quotients (l = 2^25) than the
+ * device over the five transforms.                                            */
+int godot_spectrum_frequencies(int64_t nk, double step, double scale, int divide,
+                               double *freqs, godot_stream_t stream);
+
 /* ---- direct trig sums: core.py:2426-2596 ----------------------------------- */
 
 /* power_spectrum_dft (core.py:2540-2596).  Every photon of a cell shares the

@@ -393,3 +393,19 @@ def test_transform_in_parts_equals_the_whole(lg, nbin, nparts):
         assert float((t[fin] - w[fin]).abs().max()) <= (1e-12 if nbin > 10_000 else 1e-7) * float(scale)
     with pytest.raises(Exception):
         ops.power_spectrum_rows(v_rows[:100], dc, l, edges[-2], edges[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('l,tsamp', [(1 << 14, 300.0), (1 << 23, 299.99999999), (1 << 25, 100.0), (48211, 86400.0 / 7)])
+def test_frequency_axis_is_numpys_to_the_bit(l, tsamp):
+    """np.fft.rfftfreq(l)[:l // 4 + 1] / tsamp (power_spectrum_fft, reference core.py:2677-2679) and
+    * (1 / tsamp) (power_spectrum_simple, core.py:2765-2766), formed on the device."""
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    nk = l // 4 + 1
+    ref = np.fft.rfftfreq(l)[:nk]
+    got = ops.spectrum_frequencies(nk, 1.0 / l, tsamp, True, dev).cpu().numpy()
+    assert np.array_equal(got, ref / tsamp)
+    got = ops.spectrum_frequencies(nk, 1.0 / l, 1. / tsamp, False, dev).cpu().numpy()
+    assert np.array_equal(got, ref * (1. / tsamp))
+    assert ops.spectrum_frequencies(0, 1.0 / l, tsamp, True, dev).numel() == 0
