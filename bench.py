@@ -633,6 +633,28 @@ def run_rank(args):
         extra['profile_grid'] = dict(cells_per_s=ncell / (p_ms * 1e-3), ms=p_ms,
                                      log_evals_per_s=200.0 * nph_in / (p_ms * 1e-3))
         torch.cuda.empty_cache()
+        # the C2 light curve end to end through the reference-shaped classes, wall clock: profiles of all
+        # cells (CellsLogLikelihood), then fluxes, errors and TS as host rows (get_raw_lightcurve)
+        try:
+            cells0 = data0.get_cells(tcell=args.tcell, use_barycenter=False, quiet=True)
+
+            def wall_ms(fn, n=5):
+                fn()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(n):
+                    r_ = fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n * 1e3, r_
+
+            c_ms, cll0 = wall_ms(lambda: core.CellsLogLikelihood(cells0))
+            l_ms, _ = wall_ms(cll0.get_raw_lightcurve)
+            extra['light_curve'] = dict(ncell=len(cells0), profiles_ms=c_ms, raw_lightcurve_ms=l_ms,
+                                        cells_per_s=len(cells0) / ((c_ms + l_ms) * 1e-3))
+            del cells0, cll0
+        except Exception as e:       # reported, never fatal to the headline
+            extra['light_curve'] = dict(error=repr(e))
+        torch.cuda.empty_cache()
         # dense cells (the per-source shape of C1 / C5): same photons in 2-hour cells
         dcr = data0.get_cells(tcell=7200., use_barycenter=False, quiet=True).ranges()
         ops.cell_fit(dcr)
