@@ -192,9 +192,10 @@ struct GroupCell {
 #pragma unroll
         for (int r = 0; r < R; ++r) step(w[r], r);
         for (int g = 0; g < tg; ++g) {
-            // an empty slot multiplies by f(0): 1 for every product taken here
+            // an empty slot multiplies by one
             const int j = SLOTS + 4 * g * L + q;
-            pr *= (f(tail0(j)) * f(tail0(j + L))) * (f(tail0(j + 2 * L)) * f(tail0(j + 3 * L)));
+            auto fac = [&](int jj) { return jj < n ? f(tail(jj)) : 1.0; };
+            pr *= (fac(j) * fac(j + L)) * (fac(j + 2 * L) * fac(j + 3 * L));
             if ((g & 1) != 0) {
                 ex += __builtin_amdgcn_frexp_exp(pr);
                 pr = __builtin_amdgcn_frexp_mant(pr);
