@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void cell_moments_kernel(CellArgs p, double *w
     double acc[2];
     cd.template sums<2>([](double w, double (&s)[2]) {
         s[0] += w;
-        s[1] += w * w;
+        s[1] = fma(w, w, s[1]);
     }, acc);
     if (lane == 0) {
         wsum[cell] = bad ? qnan() : acc[0];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void cell_series_kernel(CellArgs p, const doub
     double acc[2];
     cd.template sums<2>([](double w, double (&s)[2]) {
         s[0] += w;
-        s[1] += w * w;
+        s[1] = fma(w, w, s[1]);
     }, acc);
     if (lane == 0) {
         double w1 = bad ? qnan() : acc[0], w2 = bad ? qnan() : acc[1], cnt = (double)n;
@@ -244,6 +244,85 @@ __global__ __launch_bounds__(256) void cell_series_kernel(CellArgs p, const doub
         Wb[cell] = __dsub_rn(cnt, w1);
         WbWb[cell] = __dadd_rn(__dsub_rn(cnt, __dmul_rn(2.0, w1)), w2);
     }
+}
+
+// The two moments of a cell by ONE thread, for lists whose cells hold a few photons at most
+// (the 300-s bins of a time series: one photon a bin): four lanes a cell spend three quarters
+// of a wavefront on bins that hold nothing.  The additions are those of a team of four lanes
+// to the bit -- photon j goes to partial sum j mod 4, the partial sums are added as
+// (0 + 1) + (2 + 3) -- so that the series of one source do not depend on which kernel formed them.
+struct SparseMoments {
+    double w1, w2;
+    int64_t n;
+    bool bad;
+};
+
+__device__ __forceinline__ SparseMoments sparse_moments(const CellArgs &p, int64_t cell)
+{
+    const int64_t lo = p.lo[cell], hi = p.hi[cell];
+    SparseMoments m;
+    m.bad = (lo < 0) || (hi < lo) || (hi > p.nph);
+    m.n = m.bad ? 0 : hi - lo;
+    const double *w = p.we + (m.bad ? 0 : lo);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int64_t j = 0;
+    for (; j + 4 <= m.n; j += 4) {
+        const double x0 = w[j], x1 = w[j + 1], x2 = w[j + 2], x3 = w[j + 3];
+        a0 += x0;
+        b0 = fma(x0, x0, b0);
+        a1 += x1;
+        b1 = fma(x1, x1, b1);
+        a2 += x2;
+        b2 = fma(x2, x2, b2);
+        a3 += x3;
+        b3 = fma(x3, x3, b3);
+    }
+    if (j < m.n) {
+        const double x = w[j];
+        a0 += x;
+        b0 = fma(x, x, b0);
+    }
+    if (j + 1 < m.n) {
+        const double x = w[j + 1];
+        a1 += x;
+        b1 = fma(x, x, b1);
+    }
+    if (j + 2 < m.n) {
+        const double x = w[j + 2];
+        a2 += x;
+        b2 = fma(x, x, b2);
+    }
+    m.w1 = (a0 + a1) + (a2 + a3);
+    m.w2 = (b0 + b1) + (b2 + b3);
+    return m;
+}
+
+__global__ __launch_bounds__(256) void cell_moments_sparse_kernel(CellArgs p, double *wsum, double *w2sum)
+{
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= p.ncell) return;
+    const SparseMoments m = sparse_moments(p, cell);
+    wsum[cell] = m.bad ? qnan() : m.w1;
+    w2sum[cell] = m.bad ? qnan() : m.w2;
+}
+
+__global__ __launch_bounds__(256) void cell_series_sparse_kernel(CellArgs p, const double *exp, double *sexp,
+                                                                 double *bexp, double *W, double *WW, double *Wb,
+                                                                 double *WbWb)
+{
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= p.ncell) return;
+    const SparseMoments m = sparse_moments(p, cell);
+    double w1 = m.bad ? qnan() : m.w1, w2 = m.bad ? qnan() : m.w2, cnt = (double)m.n;
+    if (!(exp[cell] > 0)) {          // minimum_exposure = 0: NaN exposure empties the bin too
+        w1 = w2 = cnt = 0.0;
+        sexp[cell] = 0.0;
+        bexp[cell] = 0.0;
+    }
+    W[cell] = w1;
+    WW[cell] = w2;
+    Wb[cell] = __dsub_rn(cnt, w1);
+    WbWb[cell] = __dadd_rn(__dsub_rn(cnt, __dmul_rn(2.0, w1)), w2);
 }
 
 template <int T, int R>
@@ -929,6 +1008,13 @@ extern "C" int godot_cell_sums(const double *we, int64_t nph, const int64_t *lo,
     return GODOT_OK;
 }
 
+// fewer than three photons a cell on average and teams of four lanes otherwise: a thread a cell
+// (the same additions as the team's, see sparse_moments)
+static bool sparse_cells(int64_t nph, int64_t ncell)
+{
+    return pick_team(nph, ncell) == 0 && (double)godot_shape_photons(nph) < 3.0 * (double)ncell;
+}
+
 extern "C" int godot_cell_moments(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                                   int64_t ncell, double *wsum, double *w2sum, godot_stream_t stream)
 {
@@ -939,7 +1025,11 @@ extern "C" int godot_cell_moments(const double *we, int64_t nph, const int64_t *
     GODOT_REQUIRE(wsum && w2sum, GODOT_E_INVALID, "godot_cell_moments: null output");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, 0};
-    DISPATCH_TEAM(pick_team(nph, ncell), cell_moments_kernel, 0, p, wsum, w2sum);
+    if (sparse_cells(nph, ncell))
+        hipLaunchKernelGGL(cell_moments_sparse_kernel, dim3((unsigned)ceil_div(ncell, (int64_t)256)), dim3(256), 0, st,
+                           p, wsum, w2sum);
+    else
+        DISPATCH_TEAM(pick_team(nph, ncell), cell_moments_kernel, 0, p, wsum, w2sum);
     GODOT_LAUNCH_CHECK("godot_cell_moments");
     return GODOT_OK;
 }
@@ -955,7 +1045,11 @@ extern "C" int godot_cell_series(const double *we, int64_t nph, const int64_t *l
     GODOT_REQUIRE(exp && sexp && bexp && W && WW && Wb && WbWb, GODOT_E_INVALID, "godot_cell_series: null argument");
     hipStream_t st = (hipStream_t)stream;
     CellArgs p{we, nph, lo, hi, nullptr, nullptr, ncell, 0};
-    DISPATCH_TEAM(pick_team(nph, ncell), cell_series_kernel, 0, p, exp, sexp, bexp, W, WW, Wb, WbWb);
+    if (sparse_cells(nph, ncell))
+        hipLaunchKernelGGL(cell_series_sparse_kernel, dim3((unsigned)ceil_div(ncell, (int64_t)256)), dim3(256), 0, st,
+                           p, exp, sexp, bexp, W, WW, Wb, WbWb);
+    else
+        DISPATCH_TEAM(pick_team(nph, ncell), cell_series_kernel, 0, p, exp, sexp, bexp, W, WW, Wb, WbWb);
     GODOT_LAUNCH_CHECK("godot_cell_series");
     return GODOT_OK;
 }

@@ -1221,3 +1221,40 @@ def test_a_slice_of_a_cell_list_is_fitted_with_the_shape_of_its_own_cells():
             ar = cl.get_max()
             assert abs(_n(a)[c] - ar) <= 1e-9 * max(1.0, abs(ar))
             assert abs(_n(t)[c] - cl.get_ts(ar)) <= 1e-9 * max(-np.log1p(-we[lo[c]:hi[c]]).sum(), 1.0)
+
+
+@pytest.mark.gpu
+def test_moments_of_sparse_cells_by_a_thread_a_cell_equal_the_teams_to_the_bit():
+    """Lists of under three photons a cell take the thread-a-cell kernels (godot_cell_moments,
+    godot_cell_series); their additions are those of a team of four lanes: the same cells handed over
+    with a weight array that makes the mean look large (so that the team kernels run) give the same bits."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    ncell = 50000
+    cnt = rng.poisson(0.9, ncell).astype(np.int64)
+    cnt[rng.choice(ncell, 200, replace=False)] = rng.integers(4, 41, 200)
+    cnt[rng.choice(ncell, 20, replace=False)] = rng.integers(33, 300, 20)
+    off = np.append(0, np.cumsum(cnt)).astype(np.int64)
+    nph = int(off[-1])
+    assert nph < 3 * ncell
+    we = np.clip(rng.beta(0.3, 1.5, nph), 1e-6, 1 - 1e-6)
+    pad = np.concatenate([we, rng.random(5 * ncell - nph)])     # same cells, the mean looks like 5 photons a cell: teams of four lanes
+    lo, hi = torch.from_numpy(off[:-1].copy()).to(dev), torch.from_numpy(off[1:].copy()).to(dev)
+    w1s, w2s = ops.cell_moments(torch.from_numpy(we).to(dev), lo, hi)
+    w1t, w2t = ops.cell_moments(torch.from_numpy(pad).to(dev), lo, hi)
+    assert torch.equal(w1s, w1t) and torch.equal(w2s, w2t)
+    ref1 = np.array([we[off[c]:off[c + 1]].sum() for c in range(ncell)])
+    ref2 = np.array([(we[off[c]:off[c + 1]] ** 2).sum() for c in range(ncell)])
+    assert np.allclose(w1s.cpu().numpy(), ref1, rtol=1e-13, atol=0) and np.allclose(w2s.cpu().numpy(), ref2, rtol=1e-13, atol=0)
+    exp = rng.random(ncell)
+    exp[rng.choice(ncell, 500, replace=False)] = 0.0
+    out = []
+    for arr in (we, pad):
+        e = torch.from_numpy(exp).to(dev)
+        se, be = (e * 0.3).clone(), (e * 0.7).clone()
+        series = ops.cell_series(torch.from_numpy(arr).to(dev), lo, hi, e, se, be)
+        out.append(series + (se, be))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert float(out[0][0][torch.from_numpy(exp == 0).to(dev)].abs().max()) == 0.0
