@@ -98,6 +98,8 @@ SIGNATURES = {
     'godot_power_spectrum_fft': (c_int, [c_f64p] * 6 + [c_i64, c_i64] + [c_f64p] * 4
                                  + [c_ws, c_size, c_stream]),
     'godot_power_spectrum_from_parts': (c_int, [c_f64p] * 5 + [c_i64] + [c_f64p] * 4 + [c_stream]),
+    'godot_row_peaks_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'godot_row_peaks': (c_int, [c_f64p, c_i64, c_i64, c_i64, c_f64p, c_i64p, c_ws, c_size, c_stream]),
     'godot_spectrum_frequencies': (c_int, [c_i64, c_f64, c_f64, c_int, c_f64p, c_stream]),
     'godot_power_spectrum_simple': (c_int, [c_f64p] * 3 + [c_i64, c_f64p, c_f64p, c_ws, c_size,
                                                            c_stream]),

@@ -1831,8 +1831,9 @@ def run_sources(sources, tcell_fit, tcell_ps, tstart=None, tstop=None, chunk=32,
                 spectra.append((ls[k], samp[k], p0, p1, pb))
         join()
         if same:
-            m = torch.max(buf[:, :, 1:], 2)                          # one reduction for the chunk
-            peaks.append(torch.stack([m.values, m.indices.to(F64)], 1))
+            # one reduction for the chunk: the peak of every spectrum beyond its zero-frequency bin
+            mv, mi = ops.row_peaks(buf.view(len(part) * 3, -1), first=1)
+            peaks.append(torch.stack([mv.view(len(part), 3), mi.view(len(part), 3).to(F64)], 1))
         # (what the side streams read and wrote belongs to this stream's allocator; join() made
         # this stream wait for them, so it may be handed out again from here on)
         del W, WW, Wb, WbWb, sexp, bexp, buf

@@ -897,6 +897,106 @@ extern "C" int godot_spectrum_frequencies(int64_t nk, double step, double scale,
     return GODOT_OK;
 }
 
+namespace {
+// (value, index) pairs in the order of numpy's argmax: a NaN before any number, the larger
+// number, the smaller index among equals
+struct Peak {
+    double v;
+    int64_t i;
+};
+
+__device__ __forceinline__ bool peak_before(double v, int64_t i, double bv, int64_t bi)
+{
+    const bool nv = v != v, nb = bv != bv;
+    if (nv != nb) return nv;
+    if (!nv && v != bv) return v > bv;
+    return i < bi;
+}
+
+constexpr int PEAK_SPLIT = 64;      // workgroups a row at most
+constexpr int PEAK_CHUNK = 1 << 15; // entries a workgroup at least
+
+inline int peak_splits(int64_t ncol)
+{
+    const int64_t s = ceil_div(ncol, (int64_t)PEAK_CHUNK);
+    return (int)(s < 1 ? 1 : s > PEAK_SPLIT ? PEAK_SPLIT : s);
+}
+
+__device__ __forceinline__ Peak block_peak(Peak p, Peak *sh)
+{
+    const int t = threadIdx.x;
+    sh[t] = p;
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if (t < half) {
+            const Peak o = sh[t + half];
+            if (peak_before(o.v, o.i, sh[t].v, sh[t].i)) sh[t] = o;
+        }
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+__global__ __launch_bounds__(256) void row_peaks_part_kernel(const double *__restrict__ a, int64_t ncol, int64_t first,
+                                                             int nsplit, Peak *__restrict__ part)
+{
+    __shared__ Peak sh[256];
+    const int64_t row = blockIdx.y, n = ncol - first;
+    const int64_t per = (n + nsplit - 1) / nsplit;
+    const int64_t c0 = (int64_t)blockIdx.x * per, c1 = c0 + per < n ? c0 + per : n;
+    const double *r = a + row * ncol + first;
+    Peak best{-INFINITY, INT64_MAX};
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) {
+        const double v = r[j];
+        if (peak_before(v, j, best.v, best.i)) best = Peak{v, j};
+    }
+    best = block_peak(best, sh);
+    if (threadIdx.x == 0) part[row * nsplit + blockIdx.x] = best;
+}
+
+__global__ __launch_bounds__(256) void row_peaks_join_kernel(const Peak *__restrict__ part, int nsplit,
+                                                             double *__restrict__ values, int64_t *__restrict__ indices)
+{
+    __shared__ Peak sh[256];
+    const int64_t row = blockIdx.x;
+    Peak best{-INFINITY, INT64_MAX};
+    if ((int)threadIdx.x < nsplit) best = part[row * nsplit + threadIdx.x];
+    best = block_peak(best, sh);
+    if (threadIdx.x == 0) {
+        values[row] = best.v;
+        indices[row] = best.i;
+    }
+}
+}   // namespace
+
+extern "C" size_t godot_row_peaks_workspace_bytes(int64_t nrow, int64_t ncol)
+{
+    if (nrow <= 0 || ncol <= 0) return 0;
+    return sizeof(Peak) * (size_t)nrow * (size_t)peak_splits(ncol);
+}
+
+extern "C" int godot_row_peaks(const double *a, int64_t nrow, int64_t ncol, int64_t first, double *values,
+                               int64_t *indices, void *workspace, size_t workspace_bytes, godot_stream_t stream)
+{
+    GODOT_ENTRY();
+    GODOT_REQUIRE(nrow >= 0 && ncol >= 0, GODOT_E_INVALID, "godot_row_peaks: negative size");
+    GODOT_REQUIRE(first >= 0 && (nrow == 0 || first < ncol), GODOT_E_INVALID,
+                  "godot_row_peaks: the rows hold nothing from the first column on");
+    if (nrow == 0) return GODOT_OK;
+    GODOT_REQUIRE(a && values && indices, GODOT_E_INVALID, "godot_row_peaks: null pointer");
+    GODOT_REQUIRE(nrow <= 65535, GODOT_E_INVALID, "godot_row_peaks: more than 65 535 rows");
+    GODOT_REQUIRE(workspace && workspace_bytes >= godot_row_peaks_workspace_bytes(nrow, ncol), GODOT_E_WORKSPACE,
+                  "godot_row_peaks: workspace too small");
+    const int nsplit = peak_splits(ncol);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_peaks_part_kernel, dim3((unsigned)nsplit, (unsigned)nrow), dim3(256), 0, st, a, ncol, first,
+                       nsplit, (Peak *)workspace);
+    hipLaunchKernelGGL(row_peaks_join_kernel, dim3((unsigned)nrow), dim3(256), 0, st, (const Peak *)workspace, nsplit,
+                       values, indices);
+    GODOT_LAUNCH_CHECK("godot_row_peaks");
+    return GODOT_OK;
+}
+
 extern "C" int godot_power_spectrum_simple(const double *W, const double *WW, const double *S, int64_t n,
                                            double *dlogl, double *moments, void *workspace,
                                            size_t workspace_bytes, godot_stream_t stream)

@@ -188,6 +188,24 @@ def lightcurve_rows(tstart, tstop, alpha, ts, xlo, xhi, S, tsmin):
     return rows
 
 
+def row_peaks(a, first=0):
+    """(values, indices) of the largest entry of every row of a contiguous 2-D tensor from column
+    `first` on, the index counted from `first`: the first of equal entries, a NaN before any
+    number (numpy's argmax)."""
+    _dev_check(a, F64, 'a')
+    if a.dim() != 2 or not a.is_contiguous():
+        raise ValueError('a must be a contiguous 2-D tensor')
+    nrow, ncol = a.shape
+    dev = a.device
+    values = torch.empty(nrow, dtype=F64, device=dev)
+    indices = torch.empty(nrow, dtype=I64, device=dev)
+    ws = _workspace(_lib.lib.godot_row_peaks_workspace_bytes(nrow, ncol), dev)
+    with torch.cuda.device(dev):
+        _lib.call('godot_row_peaks', _p(a), nrow, ncol, int(first), _p(values), _p(indices), _p(ws), ws.numel(),
+                  _stream(dev))
+    return values, indices
+
+
 def spectrum_frequencies(nk, step, scale, divide, device):
     """(i * step) / scale (divide) or (i * step) * scale for i < nk: the frequency axis of
     power_spectrum_fft / power_spectrum_simple with numpy's roundings (core.py:2677-2679, 2765-2766)."""

@@ -529,6 +529,17 @@ int godot_power_spectrum_simple(const double *W, const double *WW,
 int godot_spectrum_frequencies(int64_t nk, double step, double scale, int divide,
                                double *freqs, godot_stream_t stream);
 
+/* The largest entry of every row of a [nrow][ncol] array from column `first`
+ * on, and where it stands (counted from `first`): the peak of a spectrum and
+ * its bin, what a periodicity search keeps of power_spectrum_fft's arrays
+ * (the reference's callers take numpy's max / argmax of them, e.g.
+ * paper_plots.py:396-420).  The first of equal entries, and a NaN before any
+ * number, as numpy's argmax has it.  workspace: godot_row_peaks_workspace_bytes. */
+size_t godot_row_peaks_workspace_bytes(int64_t nrow, int64_t ncol);
+int godot_row_peaks(const double *a, int64_t nrow, int64_t ncol, int64_t first,
+                    double *values, int64_t *indices,
+                    void *workspace, size_t workspace_bytes, godot_stream_t stream);
+
 /* ---- direct trig sums: core.py:2426-2596 ----------------------------------- */
 
 /* power_spectrum_dft (core.py:2540-2596).  Every photon of a cell shares the

@@ -409,3 +409,27 @@ def test_frequency_axis_is_numpys_to_the_bit(l, tsamp):
     got = ops.spectrum_frequencies(nk, 1.0 / l, 1. / tsamp, False, dev).cpu().numpy()
     assert np.array_equal(got, ref * (1. / tsamp))
     assert ops.spectrum_frequencies(0, 1.0 / l, tsamp, True, dev).numel() == 0
+
+
+@pytest.mark.gpu
+def test_row_peaks_are_numpys_max_and_argmax():
+    """godot_row_peaks: the first maximum of every row from a first column on, a NaN before any number."""
+    from godot_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    for nrow, ncol, first in [(1, 1, 0), (3, 2, 1), (7, 1000, 1), (96, 70001, 1), (5, 2_097_153, 1), (2, 300000, 17)]:
+        a = rng.standard_normal((nrow, ncol))
+        if ncol > 100:
+            a[0, [5, 90]] = a[0].max() + 1.0                  # equal maxima: the first counts
+            a[nrow - 1, ncol - 1] = 1e9                       # the last entry of the last row
+            if nrow > 2:
+                a[1, [40, 7]] = np.nan                        # a NaN before any number, the first of them
+                a[2, 0] = np.inf                              # before the first column: not looked at
+                a[2, first:] = -np.inf                        # nothing but -inf: the first entry
+        v, i = ops.row_peaks(torch.from_numpy(a).to(dev), first=first)
+        ref_i = np.argmax(a[:, first:], axis=1)
+        ref_v = a[np.arange(nrow), ref_i + first]
+        assert np.array_equal(i.cpu().numpy(), ref_i)
+        assert np.array_equal(v.cpu().numpy(), ref_v, equal_nan=True)
+    with pytest.raises(Exception):
+        ops.row_peaks(torch.zeros((2, 3), dtype=torch.float64, device=dev), first=3)
