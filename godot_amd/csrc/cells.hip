@@ -954,8 +954,9 @@ extern "C" int godot_cell_fit(const double *we, int64_t nph, const int64_t *lo, 
                                        flags, st);
     } else if (godot_detail::fit_group_shape(nph, ncell, gl, gr, false)) {
         // groups of 1 to 64 lanes per cell (cells_group.hip)
-        godot_detail::fit_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0, swap,
-                                       alpha, ts, flags, st);
+        GODOT_REQUIRE(godot_detail::fit_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, guess, guess0, beta, beta0,
+                                                     swap, alpha, ts, flags, st),
+                      GODOT_E_UNSUPPORTED, "godot_cell_fit: no kernel for the chosen shape of lane groups");
     } else if (!beta && beta0 == 1.0) {
         DISPATCH_TEAM(pick_team(nph, ncell), cell_fit_b0_kernel, 0, p, guess, guess0, beta, beta0, alpha, ts, flags);
     } else {
@@ -1094,14 +1095,16 @@ extern "C" int godot_cell_logpdf(const double *we, int64_t nph, const int64_t *l
     // enough to give every SIMD two; a workgroup per cell for very large cells and for few
     // moderately large ones
     if (group && ncell * gl >= 64 * 2048) {
-        godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
-                                          swap, dom, cod, flags, st);
+        GODOT_REQUIRE(godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt,
+                                                        include_zero, swap, dom, cod, flags, st),
+                      GODOT_E_UNSUPPORTED, "godot_cell_logpdf: no kernel for the chosen shape of lane groups");
     } else if (godot_detail::logpdf_block_cells(nph, ncell)) {
         godot_detail::logpdf_block_launch(we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero, swap, dom,
                                           cod, flags, st);
     } else if (group) {
-        godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt, include_zero,
-                                          swap, dom, cod, flags, st);
+        GODOT_REQUIRE(godot_detail::logpdf_group_launch(gl, gr, we, nph, lo, hi, S, B, ncell, aopt, dlogl, npt,
+                                                        include_zero, swap, dom, cod, flags, st),
+                      GODOT_E_UNSUPPORTED, "godot_cell_logpdf: no kernel for the chosen shape of lane groups");
     } else {
         size_t smem = (size_t)LP_CH * npt * sizeof(double);
         dim3 grid((unsigned)ceil_div(ncell, LP_CH));

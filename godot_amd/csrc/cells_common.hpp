@@ -7,7 +7,7 @@
 // sparse-cell fit kernel (cells_group.hip), launched from godot_cell_fit
 namespace godot_detail {
 bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid);
-void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+bool fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                       const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
                       const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
                       hipStream_t st);
@@ -21,7 +21,7 @@ void fit_block_launch(const double *we, int64_t nph, const int64_t *lo, const in
 void logpdf_block_launch(const double *we, int64_t nph, const int64_t *lo, const int64_t *hi, const double *S,
                          const double *B, int64_t ncell, const double *aopt, double dlogl, int npt,
                          int include_zero, int swap, double *dom, double *cod, int32_t *flags, hipStream_t st);
-void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+bool logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                          const double *S, const double *B, int64_t ncell, const double *aopt, double dlogl,
                          int npt, int include_zero, int swap, double *dom, double *cod, int32_t *flags,
                          hipStream_t st);

@@ -1035,11 +1035,12 @@ bool fit_group_shape(int64_t nph, int64_t ncell, int &L, int &R, bool grid)
     return true;
 }
 
-void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+bool fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                       const double *S, const double *B, int64_t ncell, const double *guess, double guess0,
                       const double *beta, double beta0, int swap, double *alpha, double *ts, int32_t *flags,
                       hipStream_t st)
 {
+    bool launched = false;   // a shape that fit_group_shape names and no kernel below takes must not pass in silence
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     const bool b0 = !beta && beta0 == 1.0;
     // Sparse cells restart often (1 in 10 at four photons per cell, 1 in 40 at
@@ -1050,6 +1051,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     dim3 grid2((unsigned)ceil_div(ncell, (int64_t)GK_SCAN));
 #define GK_LAUNCH_INPLACE(L_, R_)                                                                   \
     if (L == L_ && R == R_ && inplace) {                                                            \
+        launched = true;                                                                            \
         if (b0)                                                                                     \
             hipLaunchKernelGGL((cell_fit_group_b0_kernel<L_, R_, true>), grid, block, 0, st, p,     \
                                guess, guess0, beta, beta0, alpha, ts, flags);                       \
@@ -1059,6 +1061,7 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     }
 #define GK_LAUNCH_TWO(L_, R_)                                                                       \
     if (L == L_ && R == R_ && !inplace) {                                                           \
+        launched = true;                                                                            \
         if (b0) {                                                                                   \
             hipLaunchKernelGGL((cell_fit_group_b0_kernel<L_, R_, false>), grid, block, 0, st, p,    \
                                guess, guess0, beta, beta0, alpha, ts, flags);                       \
@@ -1099,19 +1102,23 @@ void fit_group_launch(int L, int R, const double *we, int64_t nph, const int64_t
     GK_LAUNCH_INPLACE(64, 32)
 #undef GK_LAUNCH_INPLACE
 #undef GK_LAUNCH_TWO
+    return launched;
 }
 
-void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
+bool logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int64_t *lo, const int64_t *hi,
                          const double *S, const double *B, int64_t ncell, const double *aopt, double dlogl,
                          int npt, int include_zero, int swap, double *dom, double *cod, int32_t *flags,
                          hipStream_t st)
 {
+    bool launched = false;
     CellArgs p{we, nph, lo, hi, S, B, ncell, swap};
     dim3 grid((unsigned)ceil_div(ncell, (int64_t)(64 / L))), block(64);
 #define GP_LAUNCH(L_, R_)                                                                             \
-    if (L == L_ && R == R_)                                                                           \
+    if (L == L_ && R == R_) {                                                                         \
+        launched = true;                                                                              \
         hipLaunchKernelGGL((cell_logpdf_group_kernel<L_, R_>), grid, block, 0, st, p, we, aopt, dlogl, \
-                           npt, include_zero, dom, cod, flags);
+                           npt, include_zero, dom, cod, flags);                                       \
+    }
     GP_LAUNCH(1, 8)
     GP_LAUNCH(1, 16)
     GP_LAUNCH(2, 12)
@@ -1136,6 +1143,7 @@ void logpdf_group_launch(int L, int R, const double *we, int64_t nph, const int6
     GP_LAUNCH(64, 24)
     GP_LAUNCH(64, 32)
 #undef GP_LAUNCH
+    return launched;
 }
 
 }   // namespace godot_detail

@@ -1258,3 +1258,30 @@ def test_moments_of_sparse_cells_by_a_thread_a_cell_equal_the_teams_to_the_bit()
     for a, b in zip(*out):
         assert torch.equal(a, b)
     assert float(out[0][0][torch.from_numpy(exp == 0).to(dev)].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_every_mean_occupancy_finds_a_kernel():
+    """The shape table of the lane-group kernels over a fine grid of photons a cell: every shape it names
+    is one a kernel was built for (the call fails otherwise), for the fit and for the profile grid, and
+    the first cell agrees with the oracle."""
+    from godot_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(21)
+    sizes = sorted(set([int(round(x)) for x in np.geomspace(1, 3200, 140)] + list(range(8, 64))))
+    for n in sizes:
+        ncell = 96
+        nph = n * ncell
+        we = np.clip(rng.beta(0.3, 1.5, nph), 1e-6, 1 - 1e-6)
+        off = (np.arange(ncell + 1) * n).astype(np.int64)
+        S = np.full(ncell, max(0.17 * n, 0.05))
+        cr = ops.CellRanges(torch.from_numpy(we).to(dev), torch.from_numpy(off[:-1].copy()).to(dev),
+                            torch.from_numpy(off[1:].copy()).to(dev), torch.from_numpy(S).to(dev),
+                            torch.from_numpy(S * 5).to(dev))
+        alpha, ts, flags = ops.cell_fit(cr)
+        dom, cod, pf = ops.cell_logpdf(cr, dlogl=30., npt=50)
+        cl = orc.CellLike(we[:n], S[0], 0.2)
+        with np.errstate(all='ignore'):
+            a = cl.get_max()
+        assert abs(float(alpha[0].cpu()) - a) <= RTOL * max(1, abs(a)), (n, float(alpha[0].cpu()), a)
+        assert bool(torch.isfinite(cod[0]).all().cpu()), n
